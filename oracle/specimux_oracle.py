@@ -759,3 +759,31 @@ def run_files(primer_file, specimen_file, sequence_file, num_seqs=-1, **kw):
         for p in op_path(op, fastq=is_fastq):
             tree.setdefault(p, []).append(op_record(op, is_fastq))
     return tree, total, matched
+
+
+# ------------------------------------------------------------------ parity helper (tests only)
+def hit_table(par, panel, rec, prefilter="auto"):
+    """Search results of match_one_end for EVERY (primer, end) of one read, in align_seq coordinates
+    (no AlignmentResult.reversed()): {(primer_name, 'A'|'B'): {'pdist', 'locs', 'barcodes': {bc: (dist, locs)}}}.
+    End 'A' searches the reverse complement, end 'B' the read itself."""
+    if prefilter == "auto":
+        prefilter = make_prefilter(panel, par) if par.prefilter else None
+    s = rec[1]
+    rs = revcomp(s)
+    out = {}
+    for primer in panel.primers.values():
+        for end, q in (("A", rs), ("B", s)):
+            c = Cand((rec[0], q, None), False, panel.b_length)
+            seen = []
+            match_one_end(prefilter, c, par, q, False, primer, 1, hits=seen)
+            _tag, _name, _e, pdist, locs = seen[0]
+            out[(primer.name, end)] = {"pdist": pdist, "locs": locs,
+                                       "barcodes": {bc: (d, list(a.locs)) for bc, a, d in c.b1}}
+    return out
+
+
+def orientation_of(par, panel, rec):
+    """determine_orientation result 'F' / 'R' / 'U' ('U' when pre-orientation is disabled)."""
+    if not par.preorient:
+        return "U"
+    return determine_orientation(par, rec[1], revcomp(rec[1]), panel.get_primers(FWD), panel.get_primers(REV))

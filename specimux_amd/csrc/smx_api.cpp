@@ -1,0 +1,452 @@
+// smx_api.cpp -- host side of libsmx.so: panel compilation, launch glue, the C ABI of include/smx.h.
+// Compiled with hipcc together with smx_kernels.hip.  No CPU implementation of the hot path lives here:
+// every compute entry point needs a HIP device and fails with SMX_ERR_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "smx.h"
+#include "smx_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) return fail(SMX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ---- IUPAC equality (reference constants.py:13-20): symmetric, NOT transitive
+struct EqTable {
+    bool eq[128][128];
+    EqTable() {
+        memset(eq, 0, sizeof(eq));
+        for (int c = 0; c < 128; c++) eq[c][c] = true;
+        const char *pairs[] = {"YC", "YT", "RA", "RG", "NA", "NC", "NG", "NT", "WA", "WT", "MA", "MC", "SC", "SG",
+                               "KG", "KT", "BC", "BG", "BT", "DA", "DG", "DT", "HA", "HC", "HT", "VA", "VC", "VG"};
+        for (const char *p : pairs) {
+            eq[(int)p[0]][(int)p[1]] = true;
+            eq[(int)p[1]][(int)p[0]] = true;
+        }
+    }
+};
+const EqTable &eqt() {
+    static EqTable t;
+    return t;
+}
+
+int code_of(unsigned char ch) {
+    for (int c = 0; c < 15; c++)
+        if (smx::kCodeChars[c] == (char)ch) return c;
+    return 15;
+}
+
+unsigned char complement_of(unsigned char ch) {   // Bio.Seq complement, ambiguous DNA table, case kept, U->A
+    static const char *from = "ACGTMRWSYKVHDBXNUacgtmrwsykvhdbxnu";
+    static const char *to = "TGCAKYWSRMBDHVXNAtgcakywsrmbdhvxna";
+    for (int i = 0; from[i]; i++)
+        if ((unsigned char)from[i] == ch) return (unsigned char)to[i];
+    return ch;
+}
+
+// bit i of peq[c] = eq(pattern[i], char of code c); code 15 never matches
+bool build_peq(const char *pat, int m, unsigned long long *peq16, std::string *bad) {
+    for (int c = 0; c < 16; c++) peq16[c] = 0;
+    for (int i = 0; i < m; i++) {
+        unsigned char pc = (unsigned char)pat[i];
+        if (pc >= 128 || code_of(pc) == 15) {
+            if (bad) *bad = std::string("pattern character '") + (char)pc + "' is outside the IUPAC DNA alphabet";
+            return false;
+        }
+        for (int c = 0; c < 15; c++)
+            if (eqt().eq[pc][(int)smx::kCodeChars[c]]) peq16[c] |= 1ull << i;
+    }
+    return true;
+}
+
+template <typename T>
+size_t blob_add(std::vector<unsigned char> &blob, const std::vector<T> &v) {
+    size_t off = (blob.size() + 15) & ~(size_t)15;
+    blob.resize(off + std::max<size_t>(v.size() * sizeof(T), 16));
+    if (!v.empty()) memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+}
+
+}  // namespace
+
+struct smx_panel {
+    smx::DevPanel hp;                 // scalar fields valid; pointers filled at upload
+    std::vector<unsigned char> blob;  // host image of the device allocation
+    size_t o_ppeq, o_prpeq, o_bpeq, o_lut, o_pm, o_pk, o_pdir, o_pfidx, o_pbc_off, o_pbc, o_bm, o_pair_f, o_pair_r,
+        o_pair_pool, o_pairhead, o_spec_next, o_p1m, o_p2m, o_spec_pool;
+    int use64 = 0;
+    int R = 0;
+    size_t lds = 0;
+    // device state (lazy, one device per process)
+    void *d_blob = nullptr;
+    int device = -1;
+    int n_cu = 0;
+    int blocks_per_cu = 1;
+};
+
+extern "C" {
+
+int smx_abi_version(void) { return SMX_ABI_VERSION; }
+const char *smx_last_error(void) { return g_err.c_str(); }
+
+int smx_device_init(int device, int *n_devices) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(SMX_ERR_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (n_devices) *n_devices = n;
+    if (device < 0 || device >= n) return fail(SMX_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    return SMX_OK;
+}
+
+int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
+    if (!d || !out) return fail(SMX_ERR_ARG, "null argument");
+    if (d->abi_version != SMX_ABI_VERSION) return fail(SMX_ERR_ARG, "ABI version mismatch: %u", d->abi_version);
+    const int NP = (int)d->n_primers, NB = (int)d->n_barcodes, NS = (int)d->n_specimens, NPAIR = (int)d->n_pairs;
+    if (NP <= 0 || NB <= 0 || NS <= 0 || NPAIR <= 0) return fail(SMX_ERR_ARG, "empty panel");
+    if (NP > 64) return fail(SMX_ERR_UNSUPPORTED, "more than 64 distinct primers (%d)", NP);
+    if (NPAIR > 127) return fail(SMX_ERR_UNSUPPORTED, "more than 127 primer pairs (%d)", NPAIR);
+    if (d->search_len < 1 || d->search_len > 256)
+        return fail(SMX_ERR_UNSUPPORTED, "search_len %d outside 1..256", d->search_len);
+    if (d->k_index < 0 || d->k_index > 32) return fail(SMX_ERR_UNSUPPORTED, "index edit distance %d outside 0..32", d->k_index);
+    if (d->trim < 0 || d->trim > 3 || d->dereplicate < 0 || d->dereplicate > 1) return fail(SMX_ERR_ARG, "bad trim/dereplicate");
+
+    smx_panel *P = new smx_panel();
+    smx::DevPanel &h = P->hp;
+    memset(&h, 0, sizeof(h));
+    h.NP = NP; h.NB = NB; h.NS = NS; h.NPAIR = NPAIR;
+    h.S = d->search_len;
+    h.wstride = ((2 * h.S) + 15) & ~15;
+    h.kidx = d->k_index;
+    h.bmax = d->barcode_len_max;
+    h.pfmin = d->prefilter_min_len;
+    h.preorient = d->preorient ? 1 : 0;
+    h.trim = d->trim;
+    h.derep = d->dereplicate;
+    h.minlen = d->min_length;
+    h.maxlen = d->max_length;
+    h.need_starts = (d->trim == SMX_TRIM_PRIMERS || d->trim == SMX_TRIM_TAILS) ? 1 : 0;
+
+    std::string bad;
+    std::vector<unsigned long long> ppeq(NP * 16), prpeq(NP * 16);
+    std::vector<int> pm(NP), pk(NP), pdir(NP), pfidx(NP), pbc_off(NP + 1);
+    int maxm = 0, maxB = 1;
+    for (int p = 0; p < NP; p++) {
+        int a = (int)d->primer_rc_off[p], m = (int)d->primer_rc_off[p + 1] - a;
+        if (m < 1 || m > 64) { delete P; return fail(SMX_ERR_UNSUPPORTED, "primer %d has length %d (supported 1..64)", p, m); }
+        std::string pat(d->primer_rc + a, m), rpat(pat.rbegin(), pat.rend());
+        if (!build_peq(pat.data(), m, &ppeq[p * 16], &bad) || !build_peq(rpat.data(), m, &prpeq[p * 16], &bad)) {
+            delete P;
+            return fail(SMX_ERR_UNSUPPORTED, "primer %d: %s", p, bad.c_str());
+        }
+        pm[p] = m;
+        pk[p] = d->primer_k[p];
+        if (pk[p] < 0 || pk[p] >= m) { delete P; return fail(SMX_ERR_UNSUPPORTED, "primer %d: edit distance %d must be in 0..len-1", p, pk[p]); }
+        pdir[p] = d->primer_dir[p] ? 1 : 0;
+        pfidx[p] = d->primer_file_index[p];
+        if (pfidx[p] < 0 || pfidx[p] > 2000) { delete P; return fail(SMX_ERR_UNSUPPORTED, "primer file index %d outside 0..2000", pfidx[p]); }
+        pbc_off[p] = (int)d->primer_bc_off[p];
+        maxm = std::max(maxm, m);
+        maxB = std::max(maxB, (int)(d->primer_bc_off[p + 1] - d->primer_bc_off[p]));
+    }
+    pbc_off[NP] = (int)d->primer_bc_off[NP];
+    if (maxB > 1024) { delete P; return fail(SMX_ERR_UNSUPPORTED, "more than 1024 barcodes on one primer (%d)", maxB); }
+    std::vector<int> pbc(std::max(pbc_off[NP], 1));
+    for (int i = 0; i < pbc_off[NP]; i++) {
+        pbc[i] = (int)d->primer_bc[i];
+        if (pbc[i] < 0 || pbc[i] >= NB) { delete P; return fail(SMX_ERR_ARG, "primer_bc[%d] out of range", i); }
+    }
+    std::vector<unsigned> bpeq(NB * 16);
+    std::vector<int> bm(NB);
+    for (int b = 0; b < NB; b++) {
+        int a = (int)d->barcode_rc_off[b], m = (int)d->barcode_rc_off[b + 1] - a;
+        if (m < 1 || m > 32) { delete P; return fail(SMX_ERR_UNSUPPORTED, "barcode %d has length %d (supported 1..32)", b, m); }
+        if (d->k_index >= m) { delete P; return fail(SMX_ERR_UNSUPPORTED, "index edit distance %d >= barcode length %d", d->k_index, m); }
+        unsigned long long t[16];
+        if (!build_peq(d->barcode_rc + a, m, t, &bad)) { delete P; return fail(SMX_ERR_UNSUPPORTED, "barcode %d: %s", b, bad.c_str()); }
+        for (int c = 0; c < 16; c++) bpeq[b * 16 + c] = (unsigned)t[c];
+        bm[b] = m;
+    }
+    if (h.pfmin != 0 && h.pfmin < 2) { delete P; return fail(SMX_ERR_UNSUPPORTED, "prefilter min length %d < 2: disable the prefilter", h.pfmin); }
+    if (h.bmax + h.kidx > 200) { delete P; return fail(SMX_ERR_UNSUPPORTED, "barcode length + k too large"); }
+    h.maxB = maxB;
+    std::vector<unsigned char> lut(512);
+    for (int c = 0; c < 256; c++) {
+        lut[c] = (unsigned char)code_of((unsigned char)c);
+        lut[256 + c] = (unsigned char)code_of(complement_of((unsigned char)c));
+    }
+    std::vector<int> pair_f(NPAIR), pair_r(NPAIR), pair_pool(NPAIR);
+    for (int i = 0; i < NPAIR; i++) {
+        pair_f[i] = (int)d->pair_fwd[i];
+        pair_r[i] = (int)d->pair_rev[i];
+        pair_pool[i] = d->pair_pool[i];
+        if (pair_f[i] >= NP || pair_r[i] >= NP || pdir[pair_f[i]] != 0 || pdir[pair_r[i]] != 1) {
+            delete P;
+            return fail(SMX_ERR_ARG, "pair %d is not (forward primer, reverse primer)", i);
+        }
+    }
+    // (b1,b2) -> chain of specimens in file order (Specimens.specimen_for_exact_match walks file order)
+    std::vector<int> pairhead((size_t)NB * NB, -1), spec_next(NS, -1), spec_pool(NS), tail((size_t)NB * NB, -1);
+    std::vector<unsigned long long> p1m(NS), p2m(NS);
+    for (int s = 0; s < NS; s++) {
+        unsigned b1 = d->spec_b1[s], b2 = d->spec_b2[s];
+        if (b1 >= (unsigned)NB || b2 >= (unsigned)NB) { delete P; return fail(SMX_ERR_ARG, "specimen %d barcode index out of range", s); }
+        size_t key = (size_t)b1 * NB + b2;
+        if (pairhead[key] < 0) pairhead[key] = s; else spec_next[tail[key]] = s;
+        tail[key] = s;
+        p1m[s] = d->spec_p1mask[s];
+        p2m[s] = d->spec_p2mask[s];
+        spec_pool[s] = d->spec_pool[s];
+    }
+    auto &B = P->blob;
+    P->o_ppeq = blob_add(B, ppeq); P->o_prpeq = blob_add(B, prpeq); P->o_bpeq = blob_add(B, bpeq); P->o_lut = blob_add(B, lut);
+    P->o_pm = blob_add(B, pm); P->o_pk = blob_add(B, pk); P->o_pdir = blob_add(B, pdir); P->o_pfidx = blob_add(B, pfidx);
+    P->o_pbc_off = blob_add(B, pbc_off); P->o_pbc = blob_add(B, pbc); P->o_bm = blob_add(B, bm);
+    P->o_pair_f = blob_add(B, pair_f); P->o_pair_r = blob_add(B, pair_r); P->o_pair_pool = blob_add(B, pair_pool);
+    P->o_pairhead = blob_add(B, pairhead); P->o_spec_next = blob_add(B, spec_next);
+    P->o_p1m = blob_add(B, p1m); P->o_p2m = blob_add(B, p2m); P->o_spec_pool = blob_add(B, spec_pool);
+
+    P->use64 = maxm > 32 ? 1 : 0;
+    // tile size: largest R in {64,...,4} whose LDS image fits the budget (3 workgroups per CU of 160 KiB)
+    const size_t budget = 52 * 1024;
+    for (int R = 64; R >= 1; R >>= 1) {
+        size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts);
+        if (need <= budget || R == 1) { P->R = R; P->lds = need; break; }
+    }
+    if (P->lds > 160 * 1024) { delete P; return fail(SMX_ERR_UNSUPPORTED, "panel needs %zu bytes of LDS per read tile", P->lds); }
+    *out = P;
+    return SMX_OK;
+}
+
+void smx_panel_destroy(smx_panel *P) {
+    if (!P) return;
+    if (P->d_blob) (void)hipFree(P->d_blob);
+    delete P;
+}
+
+size_t smx_counts_len(const smx_panel *P) { return P ? (size_t)SMX_CNT_SPECIMEN0 + P->hp.NS : 0; }
+size_t smx_window_stride(const smx_panel *P) { return P ? (size_t)P->hp.wstride : 0; }
+size_t smx_hits_per_read(const smx_panel *P) { return P ? (size_t)2 * P->hp.NP : 0; }
+size_t smx_bdist_per_read(const smx_panel *P) { return P ? (size_t)2 * P->hp.NP * P->hp.maxB : 0; }
+
+int smx_pack_windows(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int32_t S, uint8_t *windows,
+                     int32_t *lens) {
+    if (!bases || !offsets || !windows || !lens || S < 1) return fail(SMX_ERR_ARG, "null argument");
+    const size_t stride = ((size_t)(2 * S) + 15) & ~(size_t)15;
+    for (uint32_t i = 0; i < n_reads; i++) {
+        uint64_t a = offsets[i], b = offsets[i + 1];
+        if (b < a || b - a > 0x7FFFFFFFull) return fail(SMX_ERR_ARG, "read %u: bad offsets", i);
+        int L = (int)(b - a), Sp = L < S ? L : S;
+        uint8_t *w = windows + (size_t)i * stride;
+        memset(w, 0, stride);
+        memcpy(w, bases + a, (size_t)Sp);
+        memcpy(w + S, bases + b - Sp, (size_t)Sp);
+        lens[i] = L;
+    }
+    return SMX_OK;
+}
+
+static int ensure_device(smx_panel *P) {
+    if (P->d_blob) return SMX_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(SMX_ERR_DEVICE, "libsmx has no CPU path: no HIP device available (%s)", hipGetErrorString(e));
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    P->device = dev;
+    P->n_cu = prop.multiProcessorCount;
+    HIP_TRY(hipMalloc(&P->d_blob, P->blob.size()));
+    HIP_TRY(hipMemcpy(P->d_blob, P->blob.data(), P->blob.size(), hipMemcpyHostToDevice));
+    unsigned char *b = (unsigned char *)P->d_blob;
+    smx::DevPanel &h = P->hp;
+    h.ppeq = (const unsigned long long *)(b + P->o_ppeq);
+    h.prpeq = (const unsigned long long *)(b + P->o_prpeq);
+    h.bpeq = (const unsigned *)(b + P->o_bpeq);
+    h.lut = b + P->o_lut;
+    h.pm = (const int *)(b + P->o_pm); h.pk = (const int *)(b + P->o_pk);
+    h.pdir = (const int *)(b + P->o_pdir); h.pfidx = (const int *)(b + P->o_pfidx);
+    h.pbc_off = (const int *)(b + P->o_pbc_off); h.pbc = (const int *)(b + P->o_pbc); h.bm = (const int *)(b + P->o_bm);
+    h.pair_f = (const int *)(b + P->o_pair_f); h.pair_r = (const int *)(b + P->o_pair_r);
+    h.pair_pool = (const int *)(b + P->o_pair_pool);
+    h.pairhead = (const int *)(b + P->o_pairhead); h.spec_next = (const int *)(b + P->o_spec_next);
+    h.spec_p1m = (const unsigned long long *)(b + P->o_p1m); h.spec_p2m = (const unsigned long long *)(b + P->o_p2m);
+    h.spec_pool = (const int *)(b + P->o_spec_pool);
+    if (P->lds > 64 * 1024) {
+        int rc = smx_set_demux_lds_limit(P->use64, P->lds);
+        if (rc != 0) return fail(SMX_ERR_DEVICE, "cannot raise the dynamic LDS limit to %zu bytes", P->lds);
+    }
+    size_t per_cu = (160 * 1024) / std::max<size_t>(P->lds, 1);
+    P->blocks_per_cu = (int)std::min<size_t>(std::max<size_t>(per_cu, 1), 8);
+    return SMX_OK;
+}
+
+int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_windows, const int32_t *d_lens,
+                         uint32_t n_reads, smx_op *d_ops, smx_op *d_extra, uint32_t extra_cap, uint32_t *d_n_extra,
+                         uint64_t *d_counts, smx_hit *d_hits, int8_t *d_bdist) {
+    smx_panel *P = const_cast<smx_panel *>(Pc);
+    if (!P || !d_windows || !d_lens || !d_ops || !d_n_extra || !d_counts) return fail(SMX_ERR_ARG, "null argument");
+    if (extra_cap && !d_extra) return fail(SMX_ERR_ARG, "extra_cap without extra buffer");
+    if (((uintptr_t)d_windows & 15) != 0) return fail(SMX_ERR_ARG, "window buffer must be 16-byte aligned");
+    int rc = ensure_device(P);
+    if (rc) return rc;
+    if (n_reads == 0) return SMX_OK;
+    uint32_t tiles = (n_reads + P->R - 1) / P->R;
+    int grid = (int)std::min<uint32_t>(tiles, (uint32_t)(P->n_cu * P->blocks_per_cu));
+    int e = smx_launch_demux(&P->hp, P->use64, P->R, grid, P->lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
+                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist);
+    if (e != 0) return fail(SMX_ERR_DEVICE, "demux kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return SMX_OK;
+}
+
+int smx_batch_run(const smx_panel *Pc, const uint8_t *windows, const int32_t *lens, uint32_t n_reads, smx_op *ops,
+                  smx_op *extra, uint32_t extra_cap, uint32_t *n_extra, uint64_t *counts, smx_hit *hits, int8_t *bdist) {
+    smx_panel *P = const_cast<smx_panel *>(Pc);
+    if (!P || !windows || !lens || !ops || !n_extra || !counts) return fail(SMX_ERR_ARG, "null argument");
+    int rc = ensure_device(P);
+    if (rc) return rc;
+    *n_extra = 0;
+    if (n_reads == 0) return SMX_OK;
+    const size_t wbytes = (size_t)n_reads * P->hp.wstride, ncnt = smx_counts_len(P);
+    const size_t hbytes = hits ? (size_t)n_reads * smx_hits_per_read(P) * sizeof(smx_hit) : 0;
+    const size_t bbytes = bdist ? (size_t)n_reads * smx_bdist_per_read(P) : 0;
+    unsigned char *dw = nullptr, *dl = nullptr, *dop = nullptr, *dex = nullptr, *dn = nullptr, *dc = nullptr, *dh = nullptr,
+                  *db = nullptr;
+    auto cleanup = [&]() {
+        for (void *p : {(void *)dw, (void *)dl, (void *)dop, (void *)dex, (void *)dn, (void *)dc, (void *)dh, (void *)db})
+            if (p) (void)hipFree(p);
+    };
+#define TRY_C(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(SMX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); } } while (0)
+    TRY_C(hipMalloc((void **)&dw, wbytes));
+    TRY_C(hipMalloc((void **)&dl, (size_t)n_reads * 4));
+    TRY_C(hipMalloc((void **)&dop, (size_t)n_reads * sizeof(smx_op)));
+    TRY_C(hipMalloc((void **)&dex, std::max<size_t>((size_t)extra_cap * sizeof(smx_op), 32)));
+    TRY_C(hipMalloc((void **)&dn, 16));
+    TRY_C(hipMalloc((void **)&dc, ncnt * 8));
+    if (hits) TRY_C(hipMalloc((void **)&dh, hbytes));
+    if (bdist) TRY_C(hipMalloc((void **)&db, bbytes));
+    TRY_C(hipMemcpy(dw, windows, wbytes, hipMemcpyHostToDevice));
+    TRY_C(hipMemcpy(dl, lens, (size_t)n_reads * 4, hipMemcpyHostToDevice));
+    TRY_C(hipMemset(dn, 0, 16));
+    TRY_C(hipMemset(dc, 0, ncnt * 8));
+    rc = smx_batch_run_device(P, nullptr, dw, (const int32_t *)dl, n_reads, (smx_op *)dop, (smx_op *)dex, extra_cap,
+                              (uint32_t *)dn, (uint64_t *)dc, (smx_hit *)dh, (int8_t *)db);
+    if (rc) { cleanup(); return rc; }
+    TRY_C(hipDeviceSynchronize());
+    std::vector<uint64_t> c(ncnt);
+    TRY_C(hipMemcpy(ops, dop, (size_t)n_reads * sizeof(smx_op), hipMemcpyDeviceToHost));
+    TRY_C(hipMemcpy(n_extra, dn, 4, hipMemcpyDeviceToHost));
+    TRY_C(hipMemcpy(c.data(), dc, ncnt * 8, hipMemcpyDeviceToHost));
+    if (extra && extra_cap)
+        TRY_C(hipMemcpy(extra, dex, (size_t)std::min<uint32_t>(*n_extra, extra_cap) * sizeof(smx_op), hipMemcpyDeviceToHost));
+    if (hits) TRY_C(hipMemcpy(hits, dh, hbytes, hipMemcpyDeviceToHost));
+    if (bdist) TRY_C(hipMemcpy(bdist, db, bbytes, hipMemcpyDeviceToHost));
+#undef TRY_C
+    cleanup();
+    for (size_t i = 0; i < ncnt; i++) counts[i] += c[i];
+    if (c[SMX_CNT_OVERFLOW]) return fail(SMX_ERR_OVERFLOW, "%llu read(s) produced more than 16 write operations",
+                                         (unsigned long long)c[SMX_CNT_OVERFLOW]);
+    if (*n_extra > extra_cap) return fail(SMX_ERR_OVERFLOW, "extra buffer too small: need %u records, have %u", *n_extra, extra_cap);
+    return SMX_OK;
+}
+
+int smx_align(const char *query, int qlen, const char *target, int tlen, int k, int mode, int *dist, int *starts,
+              int *ends, int cap, int *nloc) {
+    if (!query || !target || !dist || !nloc) return fail(SMX_ERR_ARG, "null argument");
+    if (qlen < 1 || qlen > 64) return fail(SMX_ERR_UNSUPPORTED, "query length %d outside 1..64", qlen);
+    if (mode != 0 && mode != 1) return fail(SMX_ERR_UNSUPPORTED, "mode %d (0 = HW, 1 = SHW)", mode);
+    if (tlen < 1) return fail(SMX_ERR_UNSUPPORTED, "empty target");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(SMX_ERR_DEVICE, "libsmx has no CPU path: no HIP device");
+    unsigned long long peq[32];
+    std::string bad, q(query, qlen), rq(q.rbegin(), q.rend());
+    if (!build_peq(q.data(), qlen, peq, &bad) || !build_peq(rq.data(), qlen, peq + 16, &bad))
+        return fail(SMX_ERR_UNSUPPORTED, "%s", bad.c_str());
+    std::vector<unsigned char> codes(tlen);
+    for (int i = 0; i < tlen; i++) codes[i] = (unsigned char)code_of((unsigned char)target[i]);
+    unsigned char *d = nullptr;
+    size_t o_codes = 256, o_flag = o_codes + ((tlen + 15) & ~15), o_starts = o_flag + ((tlen + 15) & ~15),
+           o_dist = o_starts + (size_t)tlen * 4, total = o_dist + 16;
+    HIP_TRY(hipMalloc((void **)&d, total));
+    hipError_t e = hipMemcpy(d, peq, 256, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + o_codes, codes.data(), tlen, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = (hipError_t)smx_launch_align(nullptr, (unsigned long long *)d, (unsigned long long *)d + 16, qlen, d + o_codes,
+                                         tlen, k, mode, (int *)(d + o_dist), d + o_flag, (int *)(d + o_starts));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    std::vector<unsigned char> flag(tlen);
+    std::vector<int> st(tlen);
+    if (e == hipSuccess) e = hipMemcpy(dist, d + o_dist, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(flag.data(), d + o_flag, tlen, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(st.data(), d + o_starts, (size_t)tlen * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(SMX_ERR_DEVICE, "smx_align: %s", hipGetErrorString(e));
+    int cnt = 0;
+    if (*dist >= 0)
+        for (int j = 0; j < tlen; j++)
+            if (flag[j]) {
+                if (cnt < cap && starts && ends) { starts[cnt] = st[j]; ends[cnt] = j; }
+                cnt++;
+            }
+    *nloc = cnt;
+    return SMX_OK;
+}
+
+// ---- RCCL over xGMI: one communicator per process (one process per GPU)
+int smx_comm_unique_id(uint8_t id[128]) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId u;
+    ncclResult_t r = ncclGetUniqueId(&u);
+    if (r != ncclSuccess) return fail(SMX_ERR_DEVICE, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    memcpy(id, &u, 128);
+    return SMX_OK;
+}
+
+int smx_comm_init(const uint8_t id[128], int n_ranks, int rank, void **comm_out) {
+    if (!id || !comm_out) return fail(SMX_ERR_ARG, "null argument");
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    ncclComm_t comm;
+    ncclResult_t r = ncclCommInitRank(&comm, n_ranks, u, rank);
+    if (r != ncclSuccess) return fail(SMX_ERR_DEVICE, "ncclCommInitRank: %s", ncclGetErrorString(r));
+    *comm_out = (void *)comm;
+    return SMX_OK;
+}
+
+int smx_counts_allreduce(uint64_t *d_counts, size_t n, void *comm, void *stream) {
+    if (!d_counts || !comm) return fail(SMX_ERR_ARG, "null argument");
+    ncclResult_t r = ncclAllReduce(d_counts, d_counts, n, ncclUint64, ncclSum, (ncclComm_t)comm, (hipStream_t)stream);
+    if (r != ncclSuccess) return fail(SMX_ERR_DEVICE, "ncclAllReduce: %s", ncclGetErrorString(r));
+    return SMX_OK;
+}
+
+void smx_comm_destroy(void *comm) {
+    if (comm) (void)ncclCommDestroy((ncclComm_t)comm);
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// smx_internal.h -- device-side view of the panel, shared by smx_kernels.hip and smx_api.cpp.
+#ifndef SMX_INTERNAL_H
+#define SMX_INTERNAL_H
+#include <stddef.h>
+#include <stdint.h>
+#include "smx.h"
+
+namespace smx {
+
+// Text alphabet of the kernels: 16 codes.  Code 15 ("other") never matches any pattern character.
+// Order matters only for the LUTs built in smx_api.cpp.
+static const char kCodeChars[16] = {'A', 'C', 'G', 'T', 'N', 'R', 'Y', 'K', 'M', 'S', 'W', 'B', 'D', 'H', 'V', 0};
+
+// All pointers are DEVICE pointers (one allocation, see smx_api.cpp).  Passed to kernels by value.
+struct DevPanel {
+    int NP, NB, NS, NPAIR;
+    int S;            // search_len
+    int wstride;      // bytes per read in the window buffer
+    int kidx;         // max_dist_index
+    int bmax;         // Specimens.b_length()
+    int pfmin;        // prefilter min length, 0 = off
+    int preorient, trim, derep, minlen, maxlen;
+    int maxB;         // max barcodes per primer
+    int need_starts;  // HW start locations required (trim primers / tails)
+    const unsigned long long *ppeq;   // NP*16 : bit i of ppeq[p*16+c] = eq(primer_rc[i], code c)
+    const unsigned long long *prpeq;  // NP*16 : same for the reversed pattern
+    const unsigned *bpeq;             // NB*16
+    const unsigned char *lut;         // [0,256): ASCII -> code; [256,512): ASCII -> code of the complement
+    const int *pm, *pk, *pdir, *pfidx;    // per primer: pattern length, k_p, direction, file index
+    const int *pbc_off, *pbc;             // per primer barcode list (global barcode indices)
+    const int *bm;                        // per barcode length
+    const int *pair_f, *pair_r, *pair_pool;
+    const int *pairhead;                  // NB*NB: first specimen (file order) with (b1,b2), -1
+    const int *spec_next;                 // chain in file order
+    const unsigned long long *spec_p1m, *spec_p2m;
+    const int *spec_pool;
+};
+
+}  // namespace smx
+
+extern "C" {
+int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t lds_bytes, void *stream,
+                     const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops, smx_op *d_extra,
+                     uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts, smx_hit *d_hits, int8_t *d_bdist);
+size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts);
+int smx_set_demux_lds_limit(int use64, size_t bytes);
+int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,
+                     const unsigned char *d_tcodes, int n, int k, int mode, int *d_dist, unsigned char *d_endflag,
+                     int *d_starts);
+}
+#endif

@@ -1,0 +1,890 @@
+// smx_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the specimux hot path.
+//
+// One fused kernel per read batch ("demux kernel"), no intermediate HBM traffic:
+//
+//   tile of R reads per 256-thread workgroup, everything between the windows and the 32-byte
+//   result record lives in LDS:
+//     phase 0  panel (Peq tables of every primer / barcode pattern, ASCII->code LUTs) staged once per
+//              workgroup into LDS; workgroups are persistent and grid-stride over tiles
+//     phase 1  coalesced 16-byte loads of the two `search_len` end windows, ASCII -> 4-bit IUPAC code,
+//              window A reverse-complemented on the fly           (demultiplex.py:142, :757-766)
+//     phase 2  primer scan: one lane per (read, primer, end): Myers/Hyyro bit-vector HW (infix) DP,
+//              all optimal end columns kept as an LDS bitmask     (match_one_end :755-770, align_seq)
+//              + orientation votes from the same alignments       (determine_orientation :602-638, A.6)
+//     phase 3  barcode scan: one lane per (read, primer-end, optimal primer location, barcode):
+//              bit-vector SHW (prefix) DP right after the primer, exact-set prefilter rule, LDS atomicMin
+//              keeps the best location per barcode                (match_one_end :778-815, bloom_filter.py:176)
+//     phase 4  scorer: one lane per read: candidate enumeration, select_best_matches, dereplicate_*,
+//              resolve_specimen, trim extents -> smx_op records + counters
+//                                                                  (demultiplex.py:108-598, models.py:278-328)
+//
+// Pure integer work: no MFMA.  See DESIGN.md for the data layout and the roofline discussion.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "smx.h"
+#include "smx_internal.h"
+
+namespace smx {
+
+// ------------------------------------------------------------------------------------------------
+// Myers / Hyyro bit-vector column step.  Bits above the pattern length carry garbage
+// that never flows downwards (adds carry upwards, shifts go left), so no masking is needed.
+template <typename W, bool PREFIX>
+__device__ __forceinline__ void myers_step(W Eq, W &Pv, W &Mv, int &score, int top) {
+    W Xv = Eq | Mv;
+    W Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    W Ph = Mv | ~(Xh | Pv);
+    W Mh = Pv & Xh;
+    score += (int)((Ph >> top) & 1) - (int)((Mh >> top) & 1);
+    Ph = (Ph << 1) | (W)(PREFIX ? 1 : 0);
+    Mh <<= 1;
+    Pv = Mh | ~(Xv | Ph);
+    Mv = Ph & Xv;
+}
+
+// Geometry of one end string q of length L.  The stored window holds
+// q[L-Sp : L], Sp = min(S, L); window coordinate j <-> q index j + base.
+struct EndGeom {
+    int Sp;     // stored window length
+    int base;   // q index of window position 0
+    int j_lo;   // window position where match_one_end's primer target starts
+    int shift;  // reference coordinate = (j - j_lo) + shift
+};
+__device__ __forceinline__ EndGeom end_geom(int L, int S) {
+    EndGeom g;
+    g.Sp = L < S ? L : S;
+    g.base = L - g.Sp;
+    if (L >= S) { g.j_lo = 0; g.shift = L - S; }
+    else if (L == S - 1) { g.j_lo = 0; g.shift = 0; }           // start == -1 means 0 (alignment.py:37)
+    else { int lo = 2 * L - S; g.j_lo = lo > 0 ? lo : 0; g.shift = L - S; }  // negative slice start wraps
+    return g;
+}
+
+// Barcode target of align_seq(b_rc, q, k, bstart, L, SHW) (demultiplex.py:787-800) in window coordinates.
+struct BcGeom {
+    int tj0;     // window position of the first target base (may be >= Sp: empty target)
+    int delta;   // reference coordinate of window position j = j + base - delta ... see bc_abs()
+    bool pf_same; // prefilter slice sequence[bstart:] is the same string as the alignment target
+};
+__device__ __forceinline__ BcGeom bc_geom(int L, int base, int bstart) {
+    BcGeom b;
+    int s_ = (bstart == -1) ? 0 : bstart;
+    int lo = s_ < 0 ? (L + s_ > 0 ? L + s_ : 0) : (s_ < L ? s_ : L);
+    int plo = bstart < 0 ? (L + bstart > 0 ? L + bstart : 0) : (bstart < L ? bstart : L);
+    b.tj0 = lo - base;
+    b.delta = lo - s_;      // reference coordinate = q index - delta
+    b.pf_same = (plo == lo);
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-resident per (read, primer, end) record.
+struct HitL {
+    int tail_end;       // reference coord: max optimal end over all within-k barcodes, valid if bbest >= 0
+    int bfirst_end;     // reference coord: first optimal end of the first tied barcode
+    short pdist;        // -1 no primer match
+    short nloc;
+    short bbest;        // -1 none, -2 not searched
+    short ntied;
+    short first_tied;   // local index in the primer's barcode list
+    unsigned char jstar;   // window position of the first optimal primer end
+    unsigned char fs_j;    // window position of its start (need_starts only)
+    unsigned char flags;   // bit0: orientation vote, bit1: barcode search needed
+    unsigned char pad;
+};
+static_assert(sizeof(HitL) == 24, "HitL layout");
+
+#define SMX_MAX_EMIT 16
+
+struct TileLayout {   // byte offsets into dynamic LDS
+    int ppeq, prpeq, bpeq, lut, codes, lens, ocnt, hits, masks, bres, offs, emit, aggr, total;
+};
+
+template <typename PW>
+__host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, int maxB, int need_starts) {
+    TileLayout t;
+    int H = 2 * NP, MW = (S + 31) / 32;
+    int o = 0;
+    t.ppeq = o;  o += NP * 16 * (int)sizeof(PW);
+    t.prpeq = o; o += (need_starts ? NP * 16 * (int)sizeof(PW) : 0);
+    t.bpeq = o;  o += NB * 16 * 4;
+    t.lut = o;   o += 512;
+    t.codes = o; o += R * 2 * S; o = (o + 15) & ~15;
+    t.lens = o;  o += R * 4;
+    t.ocnt = o;  o += R * 2 * 4;
+    t.hits = o;  o += R * H * (int)sizeof(HitL);
+    t.masks = o; o += R * H * MW * 4;
+    t.bres = o;  o += R * H * maxB * 4;
+    t.offs = o;  o += (R * H + 1) * 4;
+    t.emit = o;  o += R * SMX_MAX_EMIT * 4;
+    t.aggr = o;  o += 8 * 4;
+    t.total = (o + 15) & ~15;
+    return t;
+}
+
+// exclusive scan of a[0..n) in LDS by wave 0 (n <= 64*chunk); a[n] = total.  Caller barriers around it.
+__device__ inline void wave0_exclusive_scan(int *a, int n) {
+    int lane = threadIdx.x;
+    if (lane >= 64) return;
+    int chunk = (n + 63) / 64;
+    int lo = lane * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += a[i];
+    int incl = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+        int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    int run = incl - sum;
+    for (int i = lo; i < hi; i++) { int v = a[i]; a[i] = run; run += v; }
+    if (lane == 63) a[n] = incl;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scorer helpers (phase 4).  Everything is indexed, nothing is string keyed.
+struct ReadCtx {
+    const DevPanel *P;
+    const HitL *hits;          // this read's H records
+    const unsigned *bres;      // this read's H*maxB packed results
+    int L, S;
+    EndGeom g;
+};
+
+struct CandView {
+    int f, r, o;               // forward primer, reverse primer, orientation 0 = as read, 1 = reverse complement
+    int h1, h2;                // hit indices (primer*2 + end)
+    bool p1, p2, b1, b2;
+    int p1d, p2d, b1d, b2d;
+};
+
+__device__ __forceinline__ CandView cand_view(const ReadCtx &c, int pair, int o) {
+    CandView v;
+    v.f = c.P->pair_f[pair];
+    v.r = c.P->pair_r[pair];
+    v.o = o;
+    v.h1 = v.f * 2 + (o == 0 ? 0 : 1);   // forward primer: end A (of rs) when the read is kept as is
+    v.h2 = v.r * 2 + (o == 0 ? 1 : 0);
+    const HitL &a = c.hits[v.h1];
+    const HitL &b = c.hits[v.h2];
+    v.p1 = a.pdist >= 0;
+    v.p2 = b.pdist >= 0;
+    v.b1 = v.p1 && a.bbest >= 0;
+    v.b2 = v.p2 && b.bbest >= 0;
+    v.p1d = v.p1 ? a.pdist : -1;
+    v.p2d = v.p2 ? b.pdist : -1;
+    v.b1d = v.b1 ? a.bbest : -1;
+    v.b2d = v.b2 ? b.bbest : -1;
+    return v;
+}
+
+__device__ __forceinline__ int cand_score(const CandView &v) {   // demultiplex.py:226-236
+    if (v.p1 && v.p2 && v.b1 && v.b2) return 5;
+    if (v.p1 && v.p2 && (v.b1 || v.b2)) return 4;
+    if ((v.p1 || v.p2) && (v.b1 || v.b2)) return 3;
+    if (v.p1 && v.p2) return 2;
+    if (v.p1 || v.p2) return 1;
+    return 0;
+}
+
+// n-th (0-based) tied barcode of hit h in canonical order -> local index; -1 when exhausted.
+__device__ inline int next_tied(const ReadCtx &c, int h, int from) {
+    const DevPanel *P = c.P;
+    int p = h >> 1;
+    int nb = P->pbc_off[p + 1] - P->pbc_off[p];
+    unsigned best = (unsigned)c.hits[h].bbest;
+    const unsigned *br = c.bres + h * P->maxB;
+    for (int i = from; i < nb; i++)
+        if ((br[i] >> 24) == best) return i;
+    return -1;
+}
+__device__ __forceinline__ int global_bc(const DevPanel *P, int h, int local) {
+    return P->pbc[P->pbc_off[h >> 1] + local];
+}
+__device__ inline bool tied_has_global(const ReadCtx &c, int h, int gb) {
+    for (int i = next_tied(c, h, 0); i >= 0; i = next_tied(c, h, i + 1))
+        if (global_bc(c.P, h, i) == gb) return true;
+    return false;
+}
+
+// Specimens.specimen_for_exact_match (databases.py:232-245): first specimen in file order.
+__device__ inline int specimen_exact(const DevPanel *P, int gb1, int gb2, int f, int r) {
+    for (int s = P->pairhead[gb1 * P->NB + gb2]; s >= 0; s = P->spec_next[s])
+        if (((P->spec_p1m[s] >> f) & 1) && ((P->spec_p2m[s] >> r) & 1)) return s;
+    return -1;
+}
+
+// Trim extents of a candidate whose stored locations were already shifted by `cum` (Q8).
+// models.py:278-319 with p1 locations mirrored by AlignmentResult.reversed (models.py:58-63).
+__device__ inline void cand_extent(const ReadCtx &c, const CandView &v, int cum, int &s, int &e) {
+    const DevPanel *P = c.P;
+    int L = c.L;
+    const HitL &a = c.hits[v.h1];
+    const HitL &b = c.hits[v.h2];
+    // first primer location in reference coordinates of the searched string
+    int a_end = 0, a_start = 0, b_end = 0, b_start = 0;
+    if (v.p1) { a_end = (int)a.jstar - c.g.j_lo + c.g.shift; a_start = (int)a.fs_j - c.g.j_lo + c.g.shift; }
+    if (v.p2) { b_end = (int)b.jstar - c.g.j_lo + c.g.shift; b_start = (int)b.fs_j - c.g.j_lo + c.g.shift; }
+    s = 0; e = L;
+    if (P->trim == SMX_TRIM_BARCODES) {
+        if (v.p1) s = (L - a_end - 1) - cum;
+        if (v.p2) e = (b_end + 1) - cum;
+    } else if (P->trim == SMX_TRIM_PRIMERS || P->trim == SMX_TRIM_TAILS) {
+        int ps = 0, pe = L;
+        if (v.p1) ps = (L - a_start - 1) + 1 - cum;
+        if (v.p2) pe = b_start - cum;
+        if (P->trim == SMX_TRIM_PRIMERS) { s = ps; e = pe; }
+        else {
+            if (v.b1) s = (L - a.tail_end - 1) - cum;
+            else { s = ps - P->bmax; if (s < 0) s = 0; }
+            if (v.b2) e = (b.tail_end + 1) - cum;
+            else { e = pe + P->bmax; if (e > L) e = L; }
+        }
+    }
+}
+
+struct Emitter {
+    const ReadCtx *c;
+    smx_op *primary;           // ops[read]
+    smx_op *extra;
+    unsigned extra_cap;
+    unsigned *n_extra;
+    unsigned long long *counts;
+    unsigned *emitlog;         // LDS: SMX_MAX_EMIT entries of (cand_id << 16 | s) ... s stored separately below
+    int *aggr;                 // LDS block aggregates
+    unsigned read;
+    int n;                     // ops emitted so far
+    bool matched;
+    bool overflow;
+};
+
+// create_write_operation (demultiplex.py:30-103) in index form.
+__device__ inline void emit_op(Emitter &E, const CandView *v, int cand_id, int sample, int rtype, int pool,
+                               int barcode, unsigned xflags) {
+    const ReadCtx &c = *E.c;
+    const DevPanel *P = c.P;
+    smx_op op;
+    op.read = E.read;
+    op.n_ops = 0;
+    op.flags = (unsigned char)xflags;
+    op.barcode = (short)barcode;
+    int s = 0, e = c.L;
+    if (v) {
+        op.dist[0] = (int8_t)v->p1d; op.dist[1] = (int8_t)v->b1d; op.dist[2] = (int8_t)v->b2d; op.dist[3] = (int8_t)v->p2d;
+        op.p1 = (short)(v->p1 ? v->f : -1);
+        op.p2 = (short)(v->p2 ? v->r : -1);
+        if (v->o) op.flags |= SMX_OPF_REVERSE;
+    } else {
+        op.dist[0] = op.dist[1] = op.dist[2] = op.dist[3] = -1;
+        op.p1 = op.p2 = -1;
+    }
+    bool fallback = false;
+    if (P->trim != SMX_TRIM_NONE) {
+        if (v) {
+            int cum = 0;   // Q8: the same CandidateMatch emitted earlier already had its locations shifted
+            int nlog = E.n < SMX_MAX_EMIT ? E.n : SMX_MAX_EMIT;
+            for (int i = 0; i < nlog; i++) {
+                unsigned w = E.emitlog[i];
+                if ((int)(w >> 24) == cand_id) cum += (int)(w & 0xFFFFFFu) - 0x800000;
+            }
+            cand_extent(c, *v, cum, s, e);
+        }
+        if (s >= e) { fallback = true; s = 0; e = c.L; }   // Q12
+    }
+    if (E.n < SMX_MAX_EMIT)
+        E.emitlog[E.n] = ((unsigned)(cand_id & 0xFF) << 24) |
+                         (unsigned)(((v && P->trim != SMX_TRIM_NONE && !fallback) ? s : 0) + 0x800000);
+    op.trim_start = s;
+    op.trim_end = e;
+    if (fallback) {
+        op.flags |= SMX_OPF_TRIM_EMPTY;
+        op.sample = -1; op.pool = -1; op.p1 = -1; op.p2 = -1; op.barcode = -1;
+        op.rtype = SMX_R_UNKNOWN;
+    } else {
+        op.sample = sample;
+        op.pool = (short)pool;
+        op.rtype = (unsigned char)rtype;
+    }
+    if (rtype == SMX_R_FULL || rtype == SMX_R_DEREP_FULL) E.matched = true;
+    // counters
+    int cls = (op.rtype == SMX_R_UNKNOWN) ? 2 : ((op.rtype == SMX_R_PARTIAL_FWD || op.rtype == SMX_R_PARTIAL_REV) ? 1 : 0);
+    atomicAdd(&E.aggr[3 + cls], 1);
+    if (cls == 0 && op.sample >= 0) atomicAdd(&E.counts[SMX_CNT_SPECIMEN0 + op.sample], 1ull);
+    if (E.n == 0) {
+        *E.primary = op;
+    } else {
+        unsigned slot = atomicAdd(E.n_extra, 1u);
+        if (slot < E.extra_cap) E.extra[slot] = op;
+    }
+    E.n++;
+    if (E.n > SMX_MAX_EMIT || cand_id > 255) E.overflow = true;
+}
+
+// resolve_specimen for a non-full candidate (demultiplex.py:576-589) -> emits.
+__device__ inline void emit_partial_or_unknown(Emitter &E, const CandView &v, int cand_id, int pool) {
+    const ReadCtx &c = *E.c;
+    if (v.b1 && !v.b2 && c.hits[v.h1].ntied == 1)
+        emit_op(E, &v, cand_id, -1, SMX_R_PARTIAL_FWD, pool, global_bc(c.P, v.h1, c.hits[v.h1].first_tied), 0);
+    else if (v.b2 && !v.b1 && c.hits[v.h2].ntied == 1)
+        emit_op(E, &v, cand_id, -1, SMX_R_PARTIAL_REV, pool, global_bc(c.P, v.h2, c.hits[v.h2].first_tied), 0);
+    else
+        emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, pool, -1, 0);
+}
+
+// Iterate the best-scoring candidates in find_candidate_matches order.
+#define FOR_BEST_CANDS(c, ori, best, ...)                                               \
+    for (int _pair = 0; _pair < (c).P->NPAIR; _pair++)                                   \
+        for (int _o = 0; _o < 2; _o++) {                                                 \
+            if ((_o == 0 && (ori) == 2) || (_o == 1 && (ori) == 1)) continue;            \
+            CandView v = cand_view((c), _pair, _o);                                      \
+            if (!(v.p1 || v.p2)) continue;                                               \
+            if (cand_score(v) != (best)) continue;                                       \
+            int cand_id = _pair * 2 + _o;                                                \
+            int cand_pool = (c).P->pair_pool[_pair];                                     \
+            (void)cand_id; (void)cand_pool;                                              \
+            __VA_ARGS__                                                                  \
+        }
+
+// key for dereplicate_matches' specimen groups (demultiplex.py:371-378); all lexicographic, small ints
+__device__ __forceinline__ int key_full(const DevPanel *P, const CandView &v) {
+    return ((v.b1d + v.b2d) << 20) | ((v.p1d + v.p2d) << 12) | (P->pfidx[v.f] + P->pfidx[v.r]);
+}
+__device__ __forceinline__ int key_partial(const DevPanel *P, const CandView &v, bool fwd) {   // :442-463
+    int cnt = (v.p1 ? 1 : 0) + (v.p2 ? 1 : 0);
+    int pd = (v.p1 ? v.p1d : 0) + (v.p2 ? v.p2d : 0);
+    int fi = (v.p1 ? P->pfidx[v.f] : 0) + (v.p2 ? P->pfidx[v.r] : 0);
+    return ((fwd ? v.b1d : v.b2d) << 24) | ((2 - cnt) << 22) | (pd << 12) | fi;
+}
+__device__ __forceinline__ int key_unknown(const DevPanel *P, const CandView &v) {             // :502-528
+    int cnt = (v.p1 ? 1 : 0) + (v.p2 ? 1 : 0);
+    int pd = (v.p1 ? v.p1d : 0) + (v.p2 ? v.p2d : 0);
+    int fi = (v.p1 ? P->pfidx[v.f] : 999) + (v.p2 ? P->pfidx[v.r] : 999);
+    return ((2 - cnt) << 22) | (pd << 12) | fi;
+}
+
+// does candidate v map some tied (b1,b2) combination to specimen `spec`?  (spec = -1: to ANY specimen)
+__device__ inline bool cand_has_specimen(const ReadCtx &c, const CandView &v, int spec) {
+    for (int i = next_tied(c, v.h1, 0); i >= 0; i = next_tied(c, v.h1, i + 1))
+        for (int j = next_tied(c, v.h2, 0); j >= 0; j = next_tied(c, v.h2, j + 1)) {
+            int s = specimen_exact(c.P, global_bc(c.P, v.h1, i), global_bc(c.P, v.h2, j), v.f, v.r);
+            if (s >= 0 && (spec < 0 || s == spec)) return true;
+        }
+    return false;
+}
+
+__device__ inline void score_read(Emitter &E, int ori) {
+    const ReadCtx &c = *E.c;
+    const DevPanel *P = c.P;
+    // ---- select_best_matches (demultiplex.py:216-259)
+    int best = 0;
+    for (int pair = 0; pair < P->NPAIR; pair++)
+        for (int o = 0; o < 2; o++) {
+            if ((o == 0 && ori == 2) || (o == 1 && ori == 1)) continue;
+            CandView v = cand_view(c, pair, o);
+            int sc = cand_score(v);
+            best = sc > best ? sc : best;
+        }
+    if (best == 0) {   // no candidate at all (demultiplex.py:202-210)
+        emit_op(E, nullptr, 0, -1, SMX_R_UNKNOWN, -1, -1, 0);
+        return;
+    }
+    if (P->derep == SMX_DEREP_NONE) {   // demultiplex.py:181-197
+        FOR_BEST_CANDS(c, ori, best, {
+            if (best == 5) {   // resolve_specimen full branch (:555-575): specimens_for_barcodes_and_primers
+                int first = -1, cnt = 0;
+                for (int i = next_tied(c, v.h1, 0); i >= 0; i = next_tied(c, v.h1, i + 1))
+                    for (int j = next_tied(c, v.h2, 0); j >= 0; j = next_tied(c, v.h2, j + 1)) {
+                        int g1 = global_bc(P, v.h1, i), g2 = global_bc(P, v.h2, j);
+                        for (int s = P->pairhead[g1 * P->NB + g2]; s >= 0; s = P->spec_next[s])
+                            if (((P->spec_p1m[s] >> v.f) & 1) && ((P->spec_p2m[s] >> v.r) & 1)) {
+                                cnt++;
+                                if (first < 0 || s < first) first = s;
+                            }
+                    }
+                if (cnt > 1) emit_op(E, &v, cand_id, first, SMX_R_MULTIPLE, P->spec_pool[first], -1, 0);
+                else if (cnt == 1) emit_op(E, &v, cand_id, first, SMX_R_FULL, P->spec_pool[first], -1, 0);
+                else emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, cand_pool, -1, SMX_OPF_NO_SPECIMEN);
+            } else {
+                emit_partial_or_unknown(E, v, cand_id, cand_pool);
+            }
+        })
+        return;
+    }
+    // ---- dereplicate_matches (demultiplex.py:262-393); the best list is homogeneous in score
+    if (best == 5) {
+        // expanded entries in order: (candidate, tied b1, tied b2) -> specimen, or one None entry per
+        // candidate without any specimen.  Groups keep first-appearance order (dict insertion).
+        bool none_done = false;
+        FOR_BEST_CANDS(c, ori, best, {
+            bool any = false;
+            for (int i = next_tied(c, v.h1, 0); i >= 0; i = next_tied(c, v.h1, i + 1))
+                for (int j = next_tied(c, v.h2, 0); j >= 0; j = next_tied(c, v.h2, j + 1)) {
+                    int spec = specimen_exact(P, global_bc(P, v.h1, i), global_bc(P, v.h2, j), v.f, v.r);
+                    if (spec < 0) continue;
+                    any = true;
+                    // first appearance of this specimen? (earlier candidate, or earlier combo of this one)
+                    bool seen = false;
+                    {
+                        const int cur_id = cand_id; const int ci = i; const int cj = j;
+                        FOR_BEST_CANDS(c, ori, best, {
+                            if (seen || cand_id > cur_id) continue;
+                            if (cand_id < cur_id) { if (cand_has_specimen(c, v, spec)) seen = true; continue; }
+                            for (int i2 = next_tied(c, v.h1, 0); i2 >= 0 && !seen; i2 = next_tied(c, v.h1, i2 + 1))
+                                for (int j2 = next_tied(c, v.h2, 0); j2 >= 0; j2 = next_tied(c, v.h2, j2 + 1)) {
+                                    if (i2 > ci || (i2 == ci && j2 >= cj)) break;
+                                    if (specimen_exact(P, global_bc(P, v.h1, i2), global_bc(P, v.h2, j2), v.f, v.r) == spec) { seen = true; break; }
+                                }
+                        })
+                    }
+                    if (seen) continue;
+                    // the group's winner: stable min of (b1d+b2d, p1d+p2d, file index sum) over its entries
+                    int wkey = 0x7FFFFFFF, wid = -1;
+                    FOR_BEST_CANDS(c, ori, best, {
+                        int k = key_full(P, v);
+                        if (k < wkey && cand_has_specimen(c, v, spec)) { wkey = k; wid = cand_id; }
+                    })
+                    CandView w = cand_view(c, wid >> 1, wid & 1);
+                    emit_op(E, &w, wid, spec, SMX_R_DEREP_FULL, P->spec_pool[spec], -1, 0);
+                }
+            if (!any && !none_done) {
+                // the None group sits where its first entry appeared; it holds every best candidate
+                // without a specimen ("other_matches", :361-363) -> resolve_specimen -> UNKNOWN (Q10)
+                none_done = true;
+                const int first_id = cand_id;
+                FOR_BEST_CANDS(c, ori, best, {
+                    if (cand_id < first_id) continue;
+                    if (!cand_has_specimen(c, v, -1))
+                        emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, cand_pool, -1, SMX_OPF_NO_SPECIMEN);
+                })
+            }
+        })
+        return;
+    }
+    if (best >= 3) {
+        // dereplicate_partial_matches (:396-477): groups keyed (direction, barcode) for every tied barcode
+        FOR_BEST_CANDS(c, ori, best, {
+            bool fwd = v.b1;
+            int h = fwd ? v.h1 : v.h2;
+            for (int i = next_tied(c, h, 0); i >= 0; i = next_tied(c, h, i + 1)) {
+                int gb = global_bc(P, h, i);
+                const int cur_id = cand_id;
+                bool seen = false;
+                int wkey = 0x7FFFFFFF, wid = -1;
+                FOR_BEST_CANDS(c, ori, best, {
+                    if (v.b1 != fwd) continue;
+                    int h2 = fwd ? v.h1 : v.h2;
+                    if (!tied_has_global(c, h2, gb)) continue;
+                    if (cand_id < cur_id) seen = true;
+                    int k = key_partial(P, v, fwd);
+                    if (k < wkey) { wkey = k; wid = cand_id; }
+                })
+                if (seen) continue;
+                CandView w = cand_view(c, wid >> 1, wid & 1);
+                emit_partial_or_unknown(E, w, wid, P->pair_pool[wid >> 1]);
+            }
+        })
+        return;
+    }
+    // dereplicate_unknown_matches (:480-538): one stable minimum
+    {
+        int wkey = 0x7FFFFFFF, wid = -1;
+        FOR_BEST_CANDS(c, ori, best, {
+            int k = key_unknown(P, v);
+            if (k < wkey) { wkey = k; wid = cand_id; }
+        })
+        CandView w = cand_view(c, wid >> 1, wid & 1);
+        emit_op(E, &w, wid, -1, SMX_R_UNKNOWN, P->pair_pool[wid >> 1], -1, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename PW>
+__global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
+                                                    const int32_t *__restrict__ lens, uint32_t n_reads, int R,
+                                                    smx_op *__restrict__ ops, smx_op *__restrict__ extra,
+                                                    uint32_t extra_cap, uint32_t *n_extra,
+                                                    unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const DevPanel *P = &Pv;
+    const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
+    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts);
+    PW *ppeq = (PW *)(lds + T.ppeq);
+    PW *prpeq = (PW *)(lds + T.prpeq);
+    unsigned *bpeq = (unsigned *)(lds + T.bpeq);
+    unsigned char *lut = lds + T.lut;
+    unsigned char *codes = lds + T.codes;
+    int *lensL = (int *)(lds + T.lens);
+    int *ocnt = (int *)(lds + T.ocnt);
+    HitL *hits = (HitL *)(lds + T.hits);
+    unsigned *masks = (unsigned *)(lds + T.masks);
+    unsigned *bres = (unsigned *)(lds + T.bres);
+    int *offs = (int *)(lds + T.offs);
+    unsigned *emitlog = (unsigned *)(lds + T.emit);
+    int *aggr = (int *)(lds + T.aggr);
+    const int tid = threadIdx.x;
+
+    // ---- phase 0: stage the panel
+    for (int i = tid; i < NP * 16; i += 256) {
+        ppeq[i] = (PW)P->ppeq[i];
+        if (P->need_starts) prpeq[i] = (PW)P->prpeq[i];
+    }
+    for (int i = tid; i < NB * 16; i += 256) bpeq[i] = P->bpeq[i];
+    for (int i = tid; i < 512; i += 256) lut[i] = P->lut[i];
+    if (tid < 8) aggr[tid] = 0;
+    __syncthreads();
+
+    const int stride = P->wstride;
+    const uint32_t n_tiles = (n_reads + R - 1) / R;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t r0 = tile * R;
+        const int nr = (int)((n_reads - r0) < (uint32_t)R ? (n_reads - r0) : (uint32_t)R);
+
+        // ---- phase 1: windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
+        if (tid < nr) { lensL[tid] = lens[r0 + tid]; ocnt[2 * tid] = 0; ocnt[2 * tid + 1] = 0; }
+        __syncthreads();
+        {
+            const int chunks = stride / 16;
+            const uint4 *src = (const uint4 *)(windows + (size_t)r0 * stride);
+            for (int ci = tid; ci < nr * chunks; ci += 256) {
+                int r = ci / chunks, cpos = (ci - r * chunks) * 16;
+                uint4 v = src[ci];
+                int L = lensL[r];
+                int Sp = L < S ? L : S;
+                unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int b = 0; b < 16; b++) {
+                    int pos = cpos + b;
+                    unsigned ch = (w[b >> 2] >> ((b & 3) * 8)) & 0xFF;
+                    if (pos < S) {            // head byte i -> A[Sp-1-i] = code(complement)
+                        if (pos < Sp) codes[(r * 2 + 0) * S + (Sp - 1 - pos)] = lut[256 + ch];
+                    } else if (pos < 2 * S) { // tail byte j -> B[j]
+                        int j = pos - S;
+                        if (j < Sp) codes[(r * 2 + 1) * S + j] = lut[ch];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: primer scan, one lane per (read, primer, end)
+        for (int item = tid; item < nr * H; item += 256) {
+            int r = item / H, h = item - r * H, p = h >> 1, X = h & 1;
+            int L = lensL[r];
+            EndGeom g = end_geom(L, S);
+            const unsigned char *cw = codes + (r * 2 + X) * S;
+            const PW *peq = ppeq + p * 16;
+            const int m = P->pm[p], k = P->pk[p], top = m - 1;
+            PW Pvv = ~(PW)0, Mv = 0;
+            int score = m, best = m + 1, jstar = 0, cnt = 0;
+            unsigned *mrow = masks + (size_t)(r * H + h) * MW;
+            for (int w = 0; w < MW; w++) {
+                unsigned word = 0;
+                int jend = (w + 1) * 32 < S ? (w + 1) * 32 : S;
+                for (int j = w * 32; j < jend; j++) {
+                    if (j >= g.j_lo && j < g.Sp) {
+                        myers_step<PW, false>(peq[cw[j]], Pvv, Mv, score, top);
+                        if (score < best) { best = score; jstar = j; cnt = 0; }
+                        if (score == best) { cnt++; word |= 1u << (j & 31); }
+                    }
+                }
+                mrow[w] = word;
+            }
+            bool matched = best <= k;
+            bool omatch = matched;
+            if (g.j_lo > 0) {   // short read: determine_orientation looks at the whole string (Q1)
+                PW P2 = ~(PW)0, M2 = 0;
+                int sc = m, b2 = m + 1;
+                for (int j = 0; j < g.Sp; j++) {
+                    myers_step<PW, false>(peq[cw[j]], P2, M2, sc, top);
+                    b2 = sc < b2 ? sc : b2;
+                }
+                omatch = b2 <= k;
+            }
+            int fs_j = jstar;
+            if (matched && P->need_starts) {
+                // edlib's start rule: SHW of the reversed pattern over the reversed target prefix,
+                // LAST optimal position = smallest start
+                const PW *rpeq = prpeq + p * 16;
+                PW P2 = ~(PW)0, M2 = 0;
+                int sc = m, lastc = 1;
+                int maxc = m + best;
+                for (int c = 1; c <= maxc; c++) {
+                    int j = jstar - (c - 1);
+                    if (j < g.j_lo) break;
+                    myers_step<PW, true>(rpeq[cw[j]], P2, M2, sc, top);
+                    if (sc == best) lastc = c;
+                }
+                fs_j = jstar - (lastc - 1);
+            }
+            HitL hl;
+            hl.tail_end = -1; hl.bfirst_end = -1;
+            hl.pdist = (short)(matched ? best : -1);
+            hl.nloc = (short)(matched ? cnt : 0);
+            hl.bbest = -2; hl.ntied = 0; hl.first_tied = -1;
+            hl.jstar = (unsigned char)jstar; hl.fs_j = (unsigned char)fs_j;
+            hl.flags = (unsigned char)(omatch ? 1 : 0); hl.pad = 0;
+            hits[r * H + h] = hl;
+            if (omatch) {
+                // determine_orientation via A.6: fwd primer in A / rev primer in B vote "forward"
+                int dir = P->pdir[p];
+                int vote_fwd = (dir == 0) ? (X == 0) : (X == 1);
+                atomicAdd(&ocnt[2 * r + (vote_fwd ? 0 : 1)], 1);
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3a: orientation, which ends need barcodes, item counts
+        for (int item = tid; item < nr * H; item += 256) {
+            int r = item / H, h = item - r * H, p = h >> 1, X = h & 1;
+            int L = lensL[r];
+            int f = ocnt[2 * r], rv = ocnt[2 * r + 1];
+            int ori = 3;   // bit0: as-read candidates allowed, bit1: reverse-complement candidates allowed
+            if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
+            bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
+            int dir = P->pdir[p];
+            bool in_fwd = (dir == 0) ? (X == 0) : (X == 1);   // used by as-read candidates
+            bool needed = !filtered && ((in_fwd && (ori & 1)) || (!in_fwd && (ori & 2)));
+            HitL &hl = hits[r * H + h];
+            int n = 0;
+            if (needed && hl.pdist >= 0) {
+                hl.flags |= 2;
+                hl.bbest = -1;
+                n = hl.nloc * (P->pbc_off[p + 1] - P->pbc_off[p]);
+            }
+            offs[item] = n;
+        }
+        for (int i = tid; i < nr * H * maxB; i += 256) bres[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        wave0_exclusive_scan(offs, nr * H);
+        __syncthreads();
+
+        // ---- phase 3b: barcode scan, one lane per (hit, location, barcode)
+        {
+            const int total = offs[nr * H];
+            const int kidx = P->kidx, pfmin = P->pfmin;
+            for (int item = tid; item < total; item += 256) {
+                int lo = 0, hi = nr * H;    // largest hh with offs[hh] <= item
+                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (offs[mid] <= item) lo = mid; else hi = mid; }
+                int hh = lo, r = hh / H, h = hh - r * H, p = h >> 1, X = h & 1;
+                int local = item - offs[hh];
+                int nb = P->pbc_off[p + 1] - P->pbc_off[p];
+                int loc_ord = local / nb, bi = local - loc_ord * nb;
+                const HitL &hl = hits[hh];
+                // loc_ord-th optimal end (bits at or after jstar)
+                const unsigned *mrow = masks + (size_t)hh * MW;
+                int je = -1, seen = 0;
+                for (int w = hl.jstar >> 5; w < MW && je < 0; w++) {
+                    unsigned word = mrow[w];
+                    if (w == (hl.jstar >> 5)) word &= ~0u << (hl.jstar & 31);
+                    int pc = __popc(word);
+                    if (seen + pc > loc_ord) {
+                        for (int t = loc_ord - seen; t > 0; t--) word &= word - 1;
+                        je = w * 32 + __ffs(word) - 1;
+                    }
+                    seen += pc;
+                }
+                int L = lensL[r];
+                EndGeom g = end_geom(L, S);
+                int bstart = (je - g.j_lo) + g.shift + 1;
+                BcGeom bg = bc_geom(L, g.base, bstart);
+                int gb = P->pbc[P->pbc_off[p] + bi];
+                int m = P->bm[gb], top = m - 1;
+                const unsigned char *cw = codes + (r * 2 + X) * S;
+                int ncol = g.Sp - bg.tj0;
+                if (ncol > m + kidx) ncol = m + kidx;
+                bool ok = ncol > 0;
+                if (ok && pfmin > 0) {   // exact-set restatement of BloomPrefilter.match (Q7)
+                    if (!bg.pf_same || g.Sp - bg.tj0 < pfmin) ok = false;
+                    else for (int c = 0; c < pfmin; c++) if (cw[bg.tj0 + c] > 3) { ok = false; break; }
+                }
+                if (!ok) continue;
+                const unsigned *peq = bpeq + gb * 16;
+                unsigned Pvv = ~0u, Mv = 0;
+                int score = m, best = m + 1, firstc = 0, lastc = 0;
+                for (int c = 0; c < ncol; c++) {
+                    myers_step<unsigned, true>(peq[cw[bg.tj0 + c]], Pvv, Mv, score, top);
+                    if (score < best) { best = score; firstc = c; }
+                    if (score == best) lastc = c;
+                }
+                if (best <= kidx)
+                    atomicMin(&bres[hh * maxB + bi], ((unsigned)best << 24) | ((unsigned)loc_ord << 16) |
+                                                         ((unsigned)(bg.tj0 + firstc) << 8) | (unsigned)(bg.tj0 + lastc));
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3c: per hit summary (best distance, tie set size, tails extent)
+        for (int item = tid; item < nr * H; item += 256) {
+            HitL &hl = hits[item];
+            if (!(hl.flags & 2)) continue;
+            int r = item / H, h = item - r * H, p = h >> 1;
+            int nb = P->pbc_off[p + 1] - P->pbc_off[p];
+            const unsigned *br = bres + item * maxB;
+            unsigned best = 255;
+            for (int i = 0; i < nb; i++) { unsigned d = br[i] >> 24; best = d < best ? d : best; }
+            if (best == 255) continue;
+            int L = lensL[r];
+            EndGeom g = end_geom(L, S);
+            int ntied = 0, first = -1, tail = -0x7FFFFFFF, bfirst = -1;
+            for (int i = 0; i < nb; i++) {
+                unsigned v = br[i];
+                if (v == 0xFFFFFFFFu) continue;
+                int delta = 0;
+                if (L < S) {   // short read: the location's slice start may have wrapped (Q1)
+                    int loc_ord = (v >> 16) & 0xFF;
+                    const unsigned *mrow = masks + (size_t)item * MW;
+                    int je = -1, seen = 0;
+                    for (int w = hl.jstar >> 5; w < MW && je < 0; w++) {
+                        unsigned word = mrow[w];
+                        if (w == (hl.jstar >> 5)) word &= ~0u << (hl.jstar & 31);
+                        int pc = __popc(word);
+                        if (seen + pc > loc_ord) {
+                            for (int t = loc_ord - seen; t > 0; t--) word &= word - 1;
+                            je = w * 32 + __ffs(word) - 1;
+                        }
+                        seen += pc;
+                    }
+                    delta = bc_geom(L, g.base, (je - g.j_lo) + g.shift + 1).delta;
+                }
+                int last_abs = (int)(v & 0xFF) + g.base - delta;
+                int first_abs = (int)((v >> 8) & 0xFF) + g.base - delta;
+                tail = last_abs > tail ? last_abs : tail;
+                if ((v >> 24) == best) { if (ntied == 0) { first = i; bfirst = first_abs; } ntied++; }
+            }
+            hl.bbest = (short)best; hl.ntied = (short)ntied; hl.first_tied = (short)first;
+            hl.tail_end = tail; hl.bfirst_end = bfirst;
+        }
+        __syncthreads();
+
+        // ---- phase 4: scorer, one lane per read (reads spread over the 4 waves)
+        {
+            int r = (tid & 63) * 4 + (tid >> 6);
+            if (r < nr) {
+                int L = lensL[r];
+                bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
+                atomicAdd(&aggr[0], 1);
+                if (filtered) {
+                    atomicAdd(&aggr[2], 1);
+                    smx_op op;
+                    op.sample = -1; op.trim_start = 0; op.trim_end = 0; op.pool = -1; op.p1 = op.p2 = -1; op.barcode = -1;
+                    op.dist[0] = op.dist[1] = op.dist[2] = op.dist[3] = -1;
+                    op.rtype = SMX_R_FILTERED; op.flags = 0; op.n_ops = 0; op.read = r0 + r;
+                    ops[r0 + r] = op;
+                } else {
+                    ReadCtx c;
+                    c.P = P; c.hits = hits + r * H; c.bres = bres + r * H * maxB; c.L = L; c.S = S; c.g = end_geom(L, S);
+                    int f = ocnt[2 * r], rv = ocnt[2 * r + 1];
+                    int ori = 3;
+                    if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
+                    Emitter E;
+                    E.c = &c; E.primary = ops + r0 + r; E.extra = extra; E.extra_cap = extra_cap; E.n_extra = n_extra;
+                    E.counts = counts; E.emitlog = emitlog + r * SMX_MAX_EMIT; E.aggr = aggr; E.read = r0 + r;
+                    E.n = 0; E.matched = false; E.overflow = false;
+                    score_read(E, ori);
+                    ops[r0 + r].n_ops = (uint16_t)E.n;
+                    if (E.matched) atomicAdd(&aggr[1], 1);
+                    if (E.n > 1) atomicAdd(&aggr[6], 1);
+                    if (E.overflow) atomicAdd(&aggr[7], 1);
+                }
+            }
+        }
+        // ---- optional parity dumps
+        if (dbg_hits) {
+            for (int item = tid; item < nr * H; item += 256) {
+                int r = item / H;
+                const HitL &hl = hits[item];
+                EndGeom g = end_geom(lensL[r], S);
+                smx_hit o;
+                o.pdist = hl.pdist; o.nloc = hl.nloc;
+                o.first_start = hl.pdist >= 0 ? (int)hl.fs_j - g.j_lo + g.shift : -1;
+                o.first_end = hl.pdist >= 0 ? (int)hl.jstar - g.j_lo + g.shift : -1;
+                o.bbest = hl.bbest; o.ntied = hl.ntied;
+                o.first_tied = (short)((hl.bbest >= 0) ? P->pbc[P->pbc_off[(item - r * H) >> 1] + hl.first_tied] : -1);
+                o.tail_end = hl.bbest >= 0 ? hl.tail_end : -1;
+                o.pad = 0;
+                dbg_hits[(size_t)(r0 + r) * H + (item - r * H)] = o;
+            }
+        }
+        if (dbg_bdist) {
+            for (int i = tid; i < nr * H * maxB; i += 256) {
+                unsigned v = bres[i];
+                dbg_bdist[(size_t)r0 * H * maxB + i] = (v == 0xFFFFFFFFu) ? (int8_t)-1 : (int8_t)(v >> 24);
+            }
+        }
+        __syncthreads();
+    }
+    // block aggregates -> global counters
+    if (tid < 8 && aggr[tid]) atomicAdd(&counts[tid], (unsigned long long)aggr[tid]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Single alignment (smx_align): one lane, same column step, arbitrary target length.
+__global__ void align_kernel(const unsigned long long *peq, const unsigned long long *rpeq, int m,
+                             const unsigned char *tcodes, int n, int k, int mode, int *out_dist,
+                             unsigned char *endflag, int *starts) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long Pv = ~0ull, Mv = 0;
+    int score = m, best = m + 1, top = m - 1;
+    for (int j = 0; j < n; j++) {
+        if (mode == 0) myers_step<unsigned long long, false>(peq[tcodes[j]], Pv, Mv, score, top);
+        else myers_step<unsigned long long, true>(peq[tcodes[j]], Pv, Mv, score, top);
+        if (score < best) best = score;
+        endflag[j] = (unsigned char)score;   // raw score, thresholded below
+    }
+    if (best > k) { *out_dist = -1; return; }
+    *out_dist = best;
+    for (int j = 0; j < n; j++) {
+        bool hit = endflag[j] == (unsigned char)best;
+        endflag[j] = hit ? 1 : 0;
+        starts[j] = 0;
+        if (hit && mode == 0) {
+            unsigned long long P2 = ~0ull, M2 = 0;
+            int sc = m, lastc = 1;
+            for (int c = 1; c <= m + best && j - (c - 1) >= 0; c++) {
+                myers_step<unsigned long long, true>(rpeq[tcodes[j - (c - 1)]], P2, M2, sc, top);
+                if (sc == best) lastc = c;
+            }
+            starts[j] = j - (lastc - 1);
+        }
+    }
+}
+
+}  // namespace smx
+
+// ------------------------------------------------------------------------------------------------
+// launch glue used by smx_api.cpp
+extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t lds_bytes, void *stream,
+                                const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops,
+                                smx_op *d_extra, uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts,
+                                smx_hit *d_hits, int8_t *d_bdist) {
+    hipStream_t s = (hipStream_t)stream;
+    if (use64)
+        hipLaunchKernelGGL(smx::demux_kernel<unsigned long long>, dim3(grid), dim3(256), lds_bytes, s, *P, d_windows,
+                           d_lens, n_reads, R, d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts,
+                           d_hits, d_bdist);
+    else
+        hipLaunchKernelGGL(smx::demux_kernel<unsigned>, dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens,
+                           n_reads, R, d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits,
+                           d_bdist);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts) {
+    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts).total
+                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts).total;
+}
+
+extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
+    hipError_t e = use64 ? hipFuncSetAttribute((const void *)smx::demux_kernel<unsigned long long>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
+                         : hipFuncSetAttribute((const void *)smx::demux_kernel<unsigned>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return (int)e;
+}
+
+extern "C" int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,
+                                const unsigned char *d_tcodes, int n, int k, int mode, int *d_dist,
+                                unsigned char *d_endflag, int *d_starts) {
+    hipLaunchKernelGGL(smx::align_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_peq, d_rpeq, m, d_tcodes, n, k,
+                       mode, d_dist, d_endflag, d_starts);
+    return (int)hipGetLastError();
+}

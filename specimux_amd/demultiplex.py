@@ -1,0 +1,121 @@
+"""process_sequences: the batch operator of the drop-in interface, executed on the GPU.
+
+Reference boundary: src/specimux/demultiplex.py:108-212 (callers multiprocessing_utils.py:89 and
+orchestration.py:513).  Same signature, same return value (write_ops, total_count, matched_count); the
+whole per-read pipeline below it runs inside one HIP kernel (specimux_amd/csrc/smx_kernels.hip) behind
+the C ABI of include/smx.h.  There is no CPU implementation here: without libsmx.so or without a GPU
+this raises."""
+import logging
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .constants import MultipleMatchStrategy, ResolutionType, SampleId, TrimMode
+from .databases import PassthroughPrefilter
+from .models import WriteOperation, reverse_complement
+from .panel import CompiledPanel
+
+
+def _prefilter_enabled(prefilter) -> bool:
+    """None / PassthroughPrefilter -> off.  A BloomPrefilter (bloom_filter.py) -> the exact-set rule in
+    the kernel.  Arbitrary user prefilters cannot run on the device."""
+    if prefilter is None or isinstance(prefilter, PassthroughPrefilter):
+        return False
+    if getattr(prefilter, "smx_exact_set", False):
+        return True
+    raise NotImplementedError(
+        f"prefilter {type(prefilter).__name__} cannot be evaluated on the GPU; pass None, "
+        "PassthroughPrefilter() or specimux_amd.bloom_filter.BloomPrefilter")
+
+
+def compiled_panel(specimens, parameters, args, prefilter) -> CompiledPanel:
+    """One CompiledPanel per distinct (panel, thresholds, flags); cached on the Specimens object."""
+    key = (id(parameters), parameters.max_dist_index, parameters.search_len, parameters.preorient,
+           tuple(sorted(parameters.max_dist_primers.items())), getattr(args, "trim", TrimMode.BARCODES),
+           getattr(args, "dereplicate", MultipleMatchStrategy.BEST), _prefilter_enabled(prefilter),
+           getattr(args, "min_length", -1), getattr(args, "max_length", -1), len(specimens._specimens))
+    cache = specimens.__dict__.setdefault("_smx_panels", {})
+    if key not in cache:
+        cache[key] = CompiledPanel(specimens, parameters, trim=key[5], dereplicate=key[6], prefilter=key[7],
+                                   min_length=key[8], max_length=key[9])
+    return cache[key]
+
+
+def concat_records(seq_records):
+    """-> (uint8 bases, uint64 offsets).  Characters outside latin-1 cannot be DNA; they become '?'."""
+    seqs = [str(r.seq) for r in seq_records]
+    offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if seqs:
+        offsets[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    blob = "".join(seqs).encode("latin-1", "replace")
+    return np.frombuffer(blob, dtype=np.uint8), offsets, seqs
+
+
+def order_ops(ops: np.ndarray, extra: np.ndarray):
+    """Yield (read_index, record) in the reference's write-op order: reads in input order, a read's
+    records in emission order (primary first, then its extra records in buffer order)."""
+    by_read = {}
+    for j in range(len(extra)):
+        by_read.setdefault(int(extra["read"][j]), []).append(j)
+    for i in range(len(ops)):
+        if ops["rtype"][i] == _lib.R_FILTERED:
+            continue
+        yield i, ops[i]
+        for j in by_read.get(i, ()):
+            yield i, extra[j]
+
+
+def op_names(panel: CompiledPanel, rec):
+    """(sample_id, pool, p1_name, p2_name, distance_code, ResolutionType) of one smx_op record."""
+    rtype = int(rec["rtype"])
+    if rec["sample"] >= 0:
+        sample = panel.specimen_ids[int(rec["sample"])]
+    elif rtype == _lib.R_PARTIAL_FWD:
+        sample = SampleId.PREFIX_FWD_MATCH + panel.barcodes[int(rec["barcode"])]
+    elif rtype == _lib.R_PARTIAL_REV:
+        sample = SampleId.PREFIX_REV_MATCH + panel.barcodes[int(rec["barcode"])]
+    else:
+        sample = SampleId.UNKNOWN
+    pool = panel.pools[int(rec["pool"])] if rec["pool"] >= 0 else "unknown"
+    p1 = panel.primer_names[int(rec["p1"])] if rec["p1"] >= 0 else "unknown"
+    p2 = panel.primer_names[int(rec["p2"])] if rec["p2"] >= 0 else "unknown"
+    code = ",".join(str(int(d)) if d >= 0 else "X" for d in rec["dist"])
+    return sample, pool, p1, p2, code, ResolutionType(rtype)
+
+
+def process_sequences(seq_records, parameters, specimens, args, prefilter, trace_logger=None,
+                      record_offset: int = 0) -> Tuple[List[WriteOperation], int, int]:
+    """Demultiplex one batch of reads on the GPU; see the module docstring."""
+    if trace_logger is not None:
+        raise NotImplementedError("trace logging (-d) is not available on the GPU path yet")
+    seq_records = list(seq_records)
+    panel = compiled_panel(specimens, parameters, args, prefilter)
+    bases, offsets, seqs = concat_records(seq_records)
+    windows, lens = panel.pack_windows(bases, offsets)
+    ops, extra, counts = panel.run(windows, lens)
+    write_ops: List[WriteOperation] = []
+    rc_cache = {}
+    for i, rec in order_ops(ops, extra):
+        record = seq_records[i]
+        sample, pool, p1, p2, code, rtype = op_names(panel, rec)
+        qual = getattr(record, "quality_string", None)
+        if qual is None:
+            ann = getattr(record, "letter_annotations", {}) or {}
+            phred = ann.get("phred_quality")
+            qual = "".join(chr(q + 33) for q in phred) if phred is not None else "I" * len(seqs[i])
+        if rec["flags"] & _lib.OPF_REVERSE:
+            if i not in rc_cache:
+                rc_cache[i] = (reverse_complement(seqs[i]), qual[::-1])
+            s, q = rc_cache[i]
+        else:
+            s, q = seqs[i], qual
+        a, b = int(rec["trim_start"]), int(rec["trim_end"])
+        s, q = s[a:b], q[a:b]
+        if rec["flags"] & _lib.OPF_NO_SPECIMEN:
+            logging.warning(f"No Specimens for combo: read {record.id} ({code}, {p1}, {p2})")
+        write_ops.append(WriteOperation(
+            sample_id=sample, seq_id=record.id, distance_code=code, sequence=s, quality_sequence=q,
+            quality_scores=[ord(c) - 33 for c in q], p1_location=None, p2_location=None, b1_location=None,
+            b2_location=None, primer_pool=pool, p1_name=p1, p2_name=p2, resolution_type=rtype))
+    return write_ops, len(seq_records), int(counts[_lib.CNT_MATCHED])

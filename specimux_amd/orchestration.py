@@ -1,0 +1,207 @@
+"""Run-level orchestration of the drop-in interface (reference: src/specimux/orchestration.py).
+
+setup_match_parameters (:548-641) derives the thresholds exactly as the reference; specimux_mp /
+specimux (:153, :458) stream the read file in large batches through process-local GPU batches instead
+of a multiprocessing.Pool of 1000-read batches.  Same log lines (`Processed N sequences, match rate: X%`,
+`Elapsed time`), same output tree."""
+import itertools
+import logging
+import math
+import os
+import timeit
+
+from .bloom_filter import BloomPrefilter, barcodes_for_bloom_prefilter
+from .constants import Primer
+from .io_utils import (OutputManager, cleanup_empty_directories, cleanup_locks, open_sequence_file,
+                       output_write_operation, read_primers_file, read_specimen_file)
+from .models import MatchParameters, reverse_complement
+
+GPU_BATCH_READS = 65536   # reads per kernel launch on the streaming path
+
+
+def edit_distance(a: str, b: str) -> int:
+    """Plain global (NW) edit distance, exact character equality (edlib.align(a, b, task='distance'),
+    orchestration.py:552) -- bit-parallel on Python integers; init-time only."""
+    if not a or not b:
+        return max(len(a), len(b))
+    peq = {}
+    for i, ch in enumerate(a):
+        peq[ch] = peq.get(ch, 0) | (1 << i)
+    m = len(a)
+    mask, top = (1 << m) - 1, 1 << (m - 1)
+    pv, mv, score = mask, 0, m
+    for ch in b:
+        eq = peq.get(ch, 0)
+        xv = eq | mv
+        xh = (((eq & pv) + pv) ^ pv) | eq
+        ph = mv | (~(xh | pv) & mask)
+        mh = pv & xh
+        if ph & top:
+            score += 1
+        elif mh & top:
+            score -= 1
+        ph = ((ph << 1) | 1) & mask
+        mh = (mh << 1) & mask
+        pv = mh | (~(xv | ph) & mask)
+        mv = ph & xv
+    return score
+
+
+def _bp_adjusted_length(primer: str) -> float:
+    weight = {**dict.fromkeys("ACGT", 3), **dict.fromkeys("KMRSWY", 2), **dict.fromkeys("BDHV", 1)}
+    return sum(weight.get(ch, 0) for ch in primer) / 3.0
+
+
+def _min_pairwise(seqs, label, args):
+    if len(seqs) <= 1:
+        return None
+    best = min(edit_distance(x, y) for x, y in itertools.combinations(seqs, 2))
+    if getattr(args, "diagnostics", None):
+        logging.info(f"Minimum edit distance is {best} for {label}")
+    return best
+
+
+def setup_match_parameters(args, specimens) -> MatchParameters:
+    fwd_bcs, rev_bcs = [], []
+    for primer in specimens.get_primers(Primer.FWD):
+        fwd_bcs.extend(b for b in primer.barcodes if b not in fwd_bcs)
+    for primer in specimens.get_primers(Primer.REV):
+        rev_bcs.extend(b for b in primer.barcodes if b not in rev_bcs)
+    _min_pairwise(fwd_bcs, "Forward Barcodes", args)
+    _min_pairwise(rev_bcs, "Reverse Barcodes", args)
+    min_bc = _min_pairwise(fwd_bcs + [reverse_complement(b) for b in rev_bcs],
+                           "Forward Barcodes + Reverse Complement of Reverse Barcodes", args)
+    all_primers = specimens.get_primers(Primer.FWD) + specimens.get_primers(Primer.REV)
+    _min_pairwise(sorted({s for p in all_primers for s in (p.primer, p.primer_rc)}),
+                  "All Primers and Reverse Complements", args)
+
+    if args.index_edit_distance != -1:
+        max_dist_index = args.index_edit_distance
+    else:
+        if min_bc is None:   # the reference dies with a TypeError here (None / 2.0): SURVEY Q14
+            raise ValueError("cannot derive the barcode edit distance from fewer than two barcodes; use -e")
+        max_dist_index = math.ceil(min_bc / 2.0)
+    logging.info(f"Using Edit Distance Thresholds {max_dist_index} for barcode indexes")
+
+    thresholds = {}
+    for primer in all_primers:
+        thresholds[primer.primer] = (args.primer_edit_distance if args.primer_edit_distance != -1
+                                     else int(_bp_adjusted_length(primer.primer) / 3))
+    for seq, k in thresholds.items():
+        logging.info(f"Using Edit Distance Threshold {k} for primer {seq}")
+    logging.info(f"Using dereplication strategy: {args.dereplicate}")
+    preorient = not args.disable_preorient
+    if not preorient:
+        logging.info("Sequence pre-orientation disabled, may run slower")
+    parameters = MatchParameters(thresholds, max_dist_index, args.search_len, preorient)
+    if not args.disable_prefilter:
+        if specimens.b_length() > 13:
+            logging.warning("Barcode prefilter not tested for barcodes longer than 13 nt.  You may need to use --disable-prefilter")
+        if max_dist_index > 3:
+            logging.warning("Barcode prefilter not tested for edit distance greater than 3.  You may need to use --disable-prefilter")
+        logging.info("Using Bloom Filter optimization for barcode matching")
+    else:
+        logging.info("Barcode prefiltering disabled, may run slower")
+    return parameters
+
+
+def _write_primer_files(directory, fwd_primers, rev_primers):
+    rows = [(p, "forward") for p in fwd_primers] + [(p, "reverse") for p in rev_primers]
+    with open(os.path.join(directory, "primers.fasta"), "w") as fa, open(os.path.join(directory, "primers.txt"), "w") as tx:
+        for p, pos in rows:
+            fa.write(f">{p.name} position={pos} pool={','.join(p.pools)}\n{p.primer}\n")
+            tx.write(f">{p.name}\n{p.primer}\n")
+
+
+def write_primers_fasta(output_dir, fwd_primer, rev_primer):
+    _write_primer_files(output_dir, [fwd_primer], [rev_primer])
+
+
+def write_all_primers_fasta(output_dir, fwd_primers, rev_primers):
+    _write_primer_files(output_dir, fwd_primers, rev_primers)
+
+
+def create_output_files(args, specimens):
+    """Directory skeleton + primers.fasta / primers.txt (orchestration.py:314-372)."""
+    if not args.output_to_files:
+        return
+    out, reg = args.output_dir, specimens._primer_registry
+    kinds = ("full", "partial", "unknown")
+    for kind in kinds:
+        os.makedirs(os.path.join(out, kind), exist_ok=True)
+    for kind in ("partial", "unknown"):
+        os.makedirs(os.path.join(out, kind, "unknown", "unknown-unknown"), exist_ok=True)
+    for pool in reg.get_pools():
+        fwd, rev = reg.get_pool_primers(pool, Primer.FWD), reg.get_pool_primers(pool, Primer.REV)
+        for kind in kinds:
+            os.makedirs(os.path.join(out, kind, pool), exist_ok=True)
+        _write_primer_files(os.path.join(out, "full", pool), fwd, rev)
+        for f in fwd:
+            for r in rev:
+                for kind in kinds:
+                    os.makedirs(os.path.join(out, kind, pool, f"{f.name}-{r.name}"), exist_ok=True)
+                _write_primer_files(os.path.join(out, "full", pool, f"{f.name}-{r.name}"), [f], [r])
+            for kind in ("partial", "unknown"):
+                os.makedirs(os.path.join(out, kind, pool, f"{f.name}-unknown"), exist_ok=True)
+        for r in rev:
+            for kind in ("partial", "unknown"):
+                os.makedirs(os.path.join(out, kind, pool, f"unknown-{r.name}"), exist_ok=True)
+
+
+def iter_batches(seq_records, batch_size: int, max_seqs: int, all_seqs: bool):
+    done = 0
+    while all_seqs or done < max_seqs:
+        want = batch_size if all_seqs else min(batch_size, max_seqs - done)
+        batch = list(itertools.islice(seq_records, want))
+        if not batch:
+            return
+        yield batch
+        done += len(batch)
+
+
+def _run(args, to_files: bool):
+    from .demultiplex import process_sequences   # needs libsmx.so: import late so --help works without it
+    registry = read_primers_file(args.primer_file)
+    specimens = read_specimen_file(args.specimen_file, registry)
+    specimens.validate()
+    parameters = setup_match_parameters(args, specimens)
+    seq_records = open_sequence_file(args.sequence_file, args)
+    create_output_files(args, specimens)
+    start = timeit.default_timer()
+    if args.start_seq > 1:
+        for _ in itertools.islice(seq_records, args.start_seq - 1):
+            pass
+    prefilter = None
+    if not args.disable_prefilter:
+        prefilter = BloomPrefilter(barcodes_for_bloom_prefilter(specimens), parameters.max_dist_index)
+    total = matched = 0
+    manager = OutputManager(args.output_dir, args.output_file_prefix, args.isfastq) if to_files else None
+    try:
+        if manager:
+            manager.__enter__()
+        for batch in iter_batches(seq_records, GPU_BATCH_READS, args.num_seqs, args.num_seqs < 0):
+            ops, n, m = process_sequences(batch, parameters, specimens, args, prefilter, None, total)
+            for op in ops:
+                output_write_operation(op, manager, args, None)
+            total += n
+            matched += m
+    finally:
+        if manager:
+            manager.close()
+    if total > 0:
+        logging.info(f"Processed {total:,} sequences, match rate: {matched / total:.1%}")
+    logging.info(f"Elapsed time: {timeit.default_timer() - start:.2f} seconds")
+    if to_files:
+        cleanup_empty_directories(args.output_dir)
+        cleanup_locks(args.output_dir)
+
+
+def specimux_mp(args):
+    """File-output entry (`-F`).  The reference forks a worker pool here; the GPU path needs no host
+    parallelism for the matching itself."""
+    _run(args, to_files=True)
+
+
+def specimux(args):
+    """stdout entry (no `-F`)."""
+    _run(args, to_files=False)

@@ -1,0 +1,318 @@
+"""GPU parity tests (run on the MI355X box: `pytest -m gpu`).  Everything goes through the C ABI of
+include/smx.h (ctypes -> libsmx.so -> HIP kernels) and is compared bit-exactly with the CPU oracle
+(oracle/), which itself is pinned to the reference's golden suite by tests/test_oracle_golden.py."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, read_expected_tree
+from parity_utils import Both, reads_from_set, tmp_panel
+
+pytestmark = pytest.mark.gpu
+
+P, S = f"{GOLDEN}/primers.fasta", f"{GOLDEN}/specimens.txt"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from specimux_amd import _lib
+    lib = _lib.load()
+    n = C.c_int(0)
+    _lib.check(lib.smx_device_init(0, C.byref(n)))
+    assert n.value >= 1
+    return lib
+
+
+def golden_reads(name):
+    from oracle import specimux_oracle as O
+    recs, _ = O.read_sequences(f"{GOLDEN}/{name}")
+    return recs
+
+
+# ------------------------------------------------------------------ the alignment primitive
+def test_smx_align_matches_oracle(lib):
+    from oracle import edlib_semantics as E
+    from specimux_amd import _lib
+    rnd = random.Random(11)
+    alpha = "ACGT" * 8 + "NRYKMSWBDHV" + "ax"
+    qalpha = "ACGT" * 6 + "NRYKMSWBDHV"
+    n_checked = 0
+    for it in range(300):
+        m = rnd.choice([1, 5, 13, 20, 23, 31, 32, 33, 47, 64])
+        n = rnd.randint(1, 120)
+        q = "".join(rnd.choice(qalpha) for _ in range(m))
+        t = "".join(rnd.choice(alpha) for _ in range(n))
+        if it % 2 == 0 and n > m:   # plant a mutated copy so that matches exist
+            pos = rnd.randint(0, n - m)
+            copy = list(q)
+            for _ in range(rnd.randint(0, 4)):
+                copy[rnd.randrange(m)] = rnd.choice("ACGT")
+            t = t[:pos] + "".join(copy) + t[pos + m:]
+        for mode, mid in ((E.HW, 0), (E.SHW, 1)):
+            k = rnd.choice([0, 1, 3, 7, m - 1]) if m > 1 else 0
+            k = min(k, m - 1)
+            exp = E.align(q, t, mode, k)
+            cap = len(t)
+            starts, ends = (C.c_int * cap)(), (C.c_int * cap)()
+            dist, nloc = C.c_int(), C.c_int()
+            _lib.check(lib.smx_align(q.encode(), len(q), t.encode("latin-1"), len(t), k, mid, C.byref(dist), starts,
+                                     ends, cap, C.byref(nloc)))
+            got = {"editDistance": dist.value, "locations": [(starts[i], ends[i]) for i in range(nloc.value)]}
+            assert got == exp, (q, t, mode, k)
+            n_checked += 1
+    assert n_checked == 600
+
+
+# ------------------------------------------------------------------ golden suite, through the GPU
+@pytest.mark.parametrize("seqfile", ["sequences.fastq", "sequences_rc.fastq"])
+def test_golden_hits_and_ops(lib, seqfile):
+    both = Both(P, S)
+    reads = golden_reads(seqfile)
+    assert both.assert_hits_equal(reads, seqfile) > 20
+    both.assert_ops_equal(reads, seqfile)
+
+
+def test_golden_tree_equals_reference_expected_output(lib, tmp_path):
+    """The reference's own integration test (tests/test_integration.py:75-114), through the CLI entry point,
+    comparing FULL records and the primers.fasta / primers.txt side files."""
+    import os
+    from specimux_amd import cli
+    out = tmp_path / "out"
+    cli.main(["specimux", P, S, f"{GOLDEN}/sequences.fastq", "-F", "-O", str(out)])
+    exp = read_expected_tree(f"{GOLDEN}/expected_output")
+    got = read_expected_tree(str(out))
+    assert got == exp
+    log = (out / "log.txt").read_text()
+    assert "Processed 40 sequences, match rate: 15.0%" in log and "Elapsed time" in log
+    for dirpath, _d, files in os.walk(f"{GOLDEN}/expected_output"):
+        for fn in files:
+            if fn.startswith("primers."):
+                rel = os.path.relpath(os.path.join(dirpath, fn), f"{GOLDEN}/expected_output")
+                assert (out / rel).read_text() == open(os.path.join(dirpath, fn)).read(), rel
+    assert not (out / "partial" / "unknown").exists()   # empty directories are pruned
+
+
+# ------------------------------------------------------------------ synthetic configs
+@pytest.fixture(scope="module")
+def c1(tmp_path_factory):
+    from specimux_amd import synth
+    pan = synth.panel_c1()
+    return pan, tmp_panel(tmp_path_factory, pan, "c1")
+
+
+@pytest.fixture(scope="module")
+def c2(tmp_path_factory):
+    from specimux_amd import synth
+    pan = synth.panel_c2()
+    return pan, tmp_panel(tmp_path_factory, pan, "c2")
+
+
+@pytest.fixture(scope="module")
+def c3(tmp_path_factory):
+    from specimux_amd import synth
+    pan = synth.panel_c3()
+    return pan, tmp_panel(tmp_path_factory, pan, "c3")
+
+
+def test_c1_plumbing_1k_reads(lib, c1):
+    from specimux_amd import synth
+    pan, (pf, sf) = c1
+    rs = synth.make_reads(pan, 1000, 1001, windows_only=False)
+    reads = reads_from_set(rs, range(1000), 80)
+    both = Both(pf, sf)
+    both.assert_hits_equal(reads[:300], "c1")
+    got = both.assert_ops_equal(reads, "c1")
+    assert sum(1 for k in got if k[6] == "DEREP") > 300      # most intact reads resolve to a specimen
+
+
+def test_c2_768_specimens(lib, c2):
+    from specimux_amd import synth
+    pan, (pf, sf) = c2
+    rs = synth.make_reads(pan, 1500, 2002, windows_only=False)
+    reads = reads_from_set(rs, range(1500), 80)
+    both = Both(pf, sf)
+    assert both.parameters.max_dist_index == 3
+    both.assert_hits_equal(reads[:250], "c2")
+    got = both.assert_ops_equal(reads, "c2")
+    # truth recovery (sanity, not exactness): intact reads get their own specimen
+    by_id = {k[0]: k for k in got if k[6] == "DEREP"}
+    ok = tot = 0
+    for i in range(1500):
+        if rs.truth["category"][i] == 0:
+            tot += 1
+            k = by_id.get(f"r{i}")
+            ok += bool(k and k[1] == f"ITS_F{rs.truth['fwd'][i]:02d}_R{rs.truth['rev'][i]:02d}")
+    assert ok / tot > 0.6
+
+
+def test_c3_four_pools_shared_primer_iupac(lib, c3):
+    from specimux_amd import synth
+    pan, (pf, sf) = c3
+    rs = synth.make_reads(pan, 1000, 3003, insert_mean=900, insert_sd=250, windows_only=False)
+    reads = reads_from_set(rs, range(1000), 80)
+    both = Both(pf, sf)
+    both.assert_hits_equal(reads[:120], "c3")
+    both.assert_ops_equal(reads, "c3")
+
+
+def test_c5_wide_window_high_error(lib, c3):
+    from specimux_amd import synth
+    pan, (pf, sf) = c3
+    rs = synth.make_reads(pan, 400, 5005, search_len=160, error_rate=0.15, windows_only=False)
+    reads = reads_from_set(rs, range(400), 160)
+    both = Both(pf, sf, search_len=160)
+    both.assert_hits_equal(reads[:80], "c5")
+    both.assert_ops_equal(reads, "c5")
+
+
+FLAG_SETS = [
+    dict(trim="none"), dict(trim="tails"), dict(trim="primers"),
+    dict(dereplicate="none"), dict(disable_preorient=True), dict(disable_prefilter=True),
+    dict(index_edit_distance=2, primer_edit_distance=4), dict(index_edit_distance=5),
+    dict(search_len=40), dict(search_len=120), dict(search_len=256), dict(min_length=300, max_length=900),
+    dict(trim="tails", dereplicate="none", disable_preorient=True, disable_prefilter=True),
+]
+
+
+@pytest.mark.parametrize("flags", FLAG_SETS, ids=lambda f: ",".join(f"{k}={v}" for k, v in f.items()))
+def test_flag_matrix(lib, c2, flags):
+    from specimux_amd import synth
+    pan, (pf, sf) = c2
+    S_ = flags.get("search_len", 80)
+    rs = synth.make_reads(pan, 400, 77, search_len=S_, windows_only=False)
+    reads = reads_from_set(rs, range(400), S_)
+    both = Both(pf, sf, **flags)
+    both.assert_hits_equal(reads[:60], str(flags))
+    both.assert_ops_equal(reads, str(flags))
+    # the golden reads too (real ONT data, gITS7 has IUPAC R)
+    gold = Both(P, S, **flags)
+    gold.assert_ops_equal(golden_reads("sequences.fastq"), f"golden {flags}")
+
+
+# ------------------------------------------------------------------ edge cases the domain has
+def _edge_reads(pan):
+    """Hand-built reads around the reference's quirks."""
+    from specimux_amd.synth import ITS1F, ITS4, revcomp
+    f0, f1, r0 = pan.fwd[0], pan.fwd[1], pan.rev[0]
+    ins = "ACGGTTCAGGCTAACGTTAGC" * 12
+    good = "TTTT" + f0 + ITS1F + ins + revcomp(ITS4) + revcomp(r0) + "GGGG"
+    reads = [
+        ("empty", ""), ("one", "A"), ("short_noprimer", "ACGT" * 10),
+        ("good", good), ("good_rc", revcomp(good)),
+        ("lower", good.lower()),                                   # Q15: reads are not upper-cased
+        ("primer_at_very_end", ins + revcomp(ITS4)),               # Q2: empty barcode target
+        ("primer_at_very_start", ITS1F + ins),
+        ("n_in_barcode", "TT" + f0[:4] + "N" + f0[5:] + ITS1F + ins + revcomp(ITS4) + revcomp(r0)),   # Q7
+        ("n_in_primer", f0 + ITS1F[:6] + "N" + ITS1F[7:] + ins + revcomp(ITS4) + revcomp(r0)),
+        ("iupac_read", f0 + ITS1F[:3] + "R" + ITS1F[4:] + ins + revcomp(ITS4) + revcomp(r0)),
+        ("both_ends_rev_primer", ITS4 + ins + revcomp(ITS4) + revcomp(r0)),      # ambiguous orientation
+        ("both_ends_fwd_primer", f0 + ITS1F + ins + revcomp(ITS1F) + revcomp(f1)),
+        ("chimera_two_fwd_barcodes", f0 + ITS1F + ins[:40] + f1 + ITS1F + ins + revcomp(ITS4) + revcomp(r0)),
+        ("u_base", "U" + good[1:]),
+    ]
+    # Q1: reads shorter than search_len that DO contain primer + barcode (every length 20..82)
+    core = f0 + ITS1F
+    for L in range(20, 83):
+        s = (core + ins)[:L]
+        reads.append((f"shortF{L}", s))
+        reads.append((f"shortR{L}", revcomp(s)))
+        t = (ins[: max(0, L - len(core) - 3)] + revcomp(ITS4) + revcomp(r0) + "ACG")[-L:]
+        reads.append((f"shortT{L}", t))
+    # tied barcodes: a target equidistant from two barcodes (Q9) -- mutate f0 towards f1 half way
+    diff = [i for i in range(len(f0)) if f0[i] != f1[i]]
+    for cut in range(1, len(diff)):
+        mid = list(f0)
+        for i in diff[:cut]:
+            mid[i] = f1[i]
+        reads.append((f"tie{cut}", "".join(mid) + ITS1F + ins + revcomp(ITS4) + revcomp(r0)))
+        reads.append((f"tie{cut}_nob2", "".join(mid) + ITS1F + ins + revcomp(ITS4)))
+    rng = np.random.default_rng(5)
+    return [(rid, s, (rng.integers(3, 41, len(s)) + 33).astype(np.uint8).tobytes().decode()) for rid, s in reads]
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(trim="tails"), dict(trim="primers"), dict(dereplicate="none"),
+                                   dict(disable_prefilter=True), dict(disable_preorient=True, index_edit_distance=5)],
+                         ids=lambda f: ",".join(f"{k}={v}" for k, v in f.items()) or "default")
+def test_edge_cases(lib, c2, flags):
+    pan, (pf, sf) = c2
+    reads = [r for r in _edge_reads(pan) if r[0] != "u_base"]
+    both = Both(pf, sf, **flags)
+    both.assert_hits_equal(reads, f"edge {flags}")
+    both.assert_ops_equal(reads, f"edge {flags}")
+
+
+def test_length_filter_emits_nothing(lib, c2):
+    pan, (pf, sf) = c2
+    reads = _edge_reads(pan)[:8]
+    both = Both(pf, sf, min_length=50)
+    got = both.assert_ops_equal(reads, "minlen")
+    assert not any(k[0] in ("empty", "one", "short_noprimer") for k in got)
+
+
+# ------------------------------------------------------------------ BASELINE-size properties
+def test_full_size_properties_765k(lib, c2):
+    """configs[1]: 768 specimens, 765k reads.  Size-independent properties + an oracle spot check."""
+    from specimux_amd import _lib, synth
+    from specimux_amd.demultiplex import compiled_panel
+    pan, (pf, sf) = c2
+    both = Both(pf, sf)
+    cp = compiled_panel(both.specimens, both.parameters, both.args, both.prefilter)
+    n = 765000
+    rs = synth.make_reads(pan, n, 2002)
+    windows = rs.windows(cp.window_stride)
+    ops, extra, counts = cp.run(windows, rs.lens)
+    # (1) counter consistency: totals, one primary record per read, specimen counters == full records
+    assert counts[_lib.CNT_TOTAL] == n and counts[_lib.CNT_FILTERED] == 0 and counts[_lib.CNT_OVERFLOW] == 0
+    allops = np.concatenate([ops, extra])
+    assert len(allops) == counts[_lib.CNT_OPS_FULL] + counts[_lib.CNT_OPS_PARTIAL] + counts[_lib.CNT_OPS_UNKNOWN]
+    assert int(ops["n_ops"].sum()) == len(allops)
+    full = allops[(allops["rtype"] == _lib.R_DEREP_FULL) & ((allops["flags"] & _lib.OPF_TRIM_EMPTY) == 0)]
+    assert np.array_equal(np.bincount(full["sample"], minlength=768), counts[_lib.CNT_SPECIMEN0:].astype(np.int64))
+    assert counts[_lib.CNT_SPECIMEN0:].sum() == counts[_lib.CNT_OPS_FULL]
+    matched_reads = np.unique(np.concatenate([ops["read"][ops["rtype"] == _lib.R_DEREP_FULL],
+                                              extra["read"][extra["rtype"] == _lib.R_DEREP_FULL]]))
+    assert len(matched_reads) == counts[_lib.CNT_MATCHED]
+    assert 0.5 < counts[_lib.CNT_MATCHED] / n < 0.9
+    # (2) determinism / idempotence
+    ops2, extra2, counts2 = cp.run(windows, rs.lens)
+    assert np.array_equal(ops, ops2) and np.array_equal(counts, counts2)
+    # (3) strand symmetry: reverse-complementing every read keeps each read's set of specimens
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[[65, 67, 71, 84]] = (84, 71, 67, 65)
+    Sp = np.minimum(rs.lens, 80)
+    j = np.arange(80)[None, :]
+    src = np.clip(Sp[:, None] - 1 - j, 0, 79)
+    rc = synth.ReadSet()
+    rc.lens = rs.lens
+    rc.head = comp[np.take_along_axis(rs.tail, src, axis=1)]
+    rc.tail = comp[np.take_along_axis(rs.head, src, axis=1)]
+    rc.head[j >= Sp[:, None]] = 0
+    rc.tail[j >= Sp[:, None]] = 0
+    ops_rc, extra_rc, counts_rc = cp.run(rc.windows(cp.window_stride), rc.lens)
+    assert np.array_equal(counts[_lib.CNT_SPECIMEN0:], counts_rc[_lib.CNT_SPECIMEN0:])
+    assert counts[_lib.CNT_MATCHED] == counts_rc[_lib.CNT_MATCHED]
+    single = (ops["n_ops"] == 1) & (ops_rc["n_ops"] == 1)
+    assert np.array_equal(ops["sample"][single], ops_rc["sample"][single])
+    assert np.array_equal(ops["dist"][single], ops_rc["dist"][single])
+    # (4) oracle spot check on a seeded sample, every category represented
+    rng = np.random.default_rng(99)
+    idx = np.sort(rng.choice(n, 1200, replace=False))
+    reads = reads_from_set(rs, idx, 80)
+    both.assert_ops_equal(reads, "765k sample")
+
+
+def test_counts_allreduce_single_rank(lib):
+    """RCCL wrapper of the C ABI with a world of one (the multi-rank path is exercised by bench.py --gpus N)."""
+    import torch
+    from specimux_amd import _lib
+    uid = (C.c_uint8 * 128)()
+    _lib.check(lib.smx_comm_unique_id(uid))
+    comm = C.c_void_p()
+    _lib.check(lib.smx_comm_init(uid, 1, 0, C.byref(comm)))
+    t = torch.arange(20, dtype=torch.int64, device="cuda")
+    _lib.check(lib.smx_counts_allreduce(C.c_void_p(t.data_ptr()), 20, comm, None))
+    torch.cuda.synchronize()
+    assert t.cpu().tolist() == list(range(20))
+    lib.smx_comm_destroy(comm)

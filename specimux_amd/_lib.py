@@ -82,6 +82,14 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: the HIP extension was not built. specimux_amd has no CPU fallback; "
                 "run `make -C specimux_amd/csrc` (needs hipcc, targets gfx950).")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64 / libhsa-runtime64 / librccl (same
+        # sonames as /opt/rocm's).  If torch is imported AFTER libsmx.so pulled in /opt/rocm's copies, two HSA
+        # runtimes end up in the process and the second one finds no GPU.  Importing torch first makes the loader
+        # resolve libsmx.so's NEEDED entries to the copies torch already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)   # AttributeError if the library does not export the symbol

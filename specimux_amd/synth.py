@@ -144,6 +144,19 @@ def _rc_rows(arr, lens):
     return out
 
 
+def rebuild_read(head, tail, L, S):
+    """A read with the given end windows and length: head + filler + tail.  The hot path reads nothing but the
+    two windows and the length, so any consumer of full reads (the oracle) sees the same problem."""
+    Sp = min(S, L)
+    h = head[:Sp].tobytes().decode()
+    t = tail[:Sp].tobytes().decode()
+    if L <= S:
+        return h
+    if L < 2 * S:
+        return h + t[2 * S - L:]
+    return h + "A" * (L - 2 * S) + t
+
+
 class ReadSet:
     """Generated reads.  Always holds the end windows; holds full reads only when windows_only=False."""
 

@@ -125,16 +125,7 @@ class Both:
         return checked
 
 
-def rebuild_read(head, tail, L, S):
-    """A read with the given end windows and length (the hot path reads nothing else): head + filler + tail."""
-    Sp = min(S, L)
-    h = head[:Sp].tobytes().decode()
-    t = tail[:Sp].tobytes().decode()
-    if L <= S:
-        return h
-    if L < 2 * S:
-        return h + t[2 * S - L:]
-    return h + "A" * (L - 2 * S) + t
+from specimux_amd.synth import rebuild_read  # noqa: E402,F401
 
 
 def reads_from_set(rs, idx, S, prefix="r"):

@@ -57,11 +57,24 @@ def _cpu_work(reads):
     return total, matched
 
 
+def host_cores():
+    """CPU share of this process: cgroup quota if one is set, else the affinity mask; capped at 64 workers."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 64)
+
+
 def cpu_baseline(pf, sf, rs, budget_reads_per_core=12000):
     """Reference-shaped CPU path (the oracle) on a bounded sample, all host cores, 1000-read batches like the
     reference's worker pool (orchestration.py:165)."""
     from specimux_amd.synth import rebuild_read
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     n = min(len(rs.lens), budget_reads_per_core * cores)
     reads = [(f"r{i}", rebuild_read(rs.head[i], rs.tail[i], int(rs.lens[i]), SEARCH_LEN), None) for i in range(n)]
     reads = [(i, s, "I" * len(s)) for i, s, _ in reads]

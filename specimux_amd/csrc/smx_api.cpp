@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -105,6 +106,9 @@ struct smx_panel {
     int device = -1;
     int n_cu = 0;
     int blocks_per_cu = 1;
+    unsigned *d_tile_counter = nullptr;      // dynamic tile queue head (zeroed on the stream before each launch)
+    unsigned long long *d_phase = nullptr;   // SMX_PHASE_TIMING diagnostic
+    int phase_grid = 0;
 };
 
 extern "C" {
@@ -193,6 +197,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     if (h.pfmin != 0 && h.pfmin < 2) { delete P; return fail(SMX_ERR_UNSUPPORTED, "prefilter min length %d < 2: disable the prefilter", h.pfmin); }
     if (h.bmax + h.kidx > 200) { delete P; return fail(SMX_ERR_UNSUPPORTED, "barcode length + k too large"); }
     h.maxB = maxB;
+    h.n_pbc = pbc_off[NP];
     std::vector<unsigned char> lut(512);
     for (int c = 0; c < 256; c++) {
         lut[c] = (unsigned char)code_of((unsigned char)c);
@@ -230,10 +235,15 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     P->o_p1m = blob_add(B, p1m); P->o_p2m = blob_add(B, p2m); P->o_spec_pool = blob_add(B, spec_pool);
 
     P->use64 = maxm > 32 ? 1 : 0;
-    // tile size: largest R in {64,...,4} whose LDS image fits the budget (3 workgroups per CU of 160 KiB)
-    const size_t budget = 52 * 1024;
-    for (int R = 64; R >= 1; R >>= 1) {
-        size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts);
+    // tile size: largest R in {64, 32, ...} whose LDS image lets 3 workgroups share a CU's 160 KiB
+    // (SMX_TILE_R / SMX_LDS_BUDGET override for tuning experiments)
+    size_t budget = (160 * 1024) / 3;
+    if (const char *e = getenv("SMX_LDS_BUDGET")) budget = (size_t)atol(e);
+    int rmax = 64;
+    if (const char *e = getenv("SMX_TILE_R")) rmax = std::max(1, std::min(64, atoi(e)));
+    for (int R = rmax; R >= 1; R >>= 1) {
+        size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts,
+                                          5 * NP + 1 + h.n_pbc + NB + 3 * NPAIR);
         if (need <= budget || R == 1) { P->R = R; P->lds = need; break; }
     }
     if (P->lds > 160 * 1024) { delete P; return fail(SMX_ERR_UNSUPPORTED, "panel needs %zu bytes of LDS per read tile", P->lds); }
@@ -243,7 +253,22 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
 
 void smx_panel_destroy(smx_panel *P) {
     if (!P) return;
+    if (P->d_phase) {   // diagnostic: print the per-phase share of block cycles
+        std::vector<unsigned long long> h((size_t)P->phase_grid * 16);
+        if (hipMemcpy(h.data(), P->d_phase, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long sum[10] = {0}, tot = 0;
+            for (int b = 0; b < P->phase_grid; b++)
+                for (int i = 0; i < 10; i++) { sum[i] += h[(size_t)b * 16 + i]; tot += h[(size_t)b * 16 + i]; }
+            const char *names[8] = {"load+encode", "primer_scan", "orient+scan", "entries", "barcode_scan", "summary",
+                                    "scorer", "store"};
+            fprintf(stderr, "[smx phase timing] R=%d lds=%zu blocks/CU=%d:", P->R, P->lds, P->blocks_per_cu);
+            for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.1f%%", names[i], tot ? 100.0 * sum[i] / tot : 0.0);
+            fprintf(stderr, "\n");
+        }
+        (void)hipFree(P->d_phase);
+    }
     if (P->d_blob) (void)hipFree(P->d_blob);
+    if (P->d_tile_counter) (void)hipFree(P->d_tile_counter);
     delete P;
 }
 
@@ -283,6 +308,7 @@ static int ensure_device(smx_panel *P) {
     P->n_cu = prop.multiProcessorCount;
     HIP_TRY(hipMalloc(&P->d_blob, P->blob.size()));
     HIP_TRY(hipMemcpy(P->d_blob, P->blob.data(), P->blob.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&P->d_tile_counter, 64));
     unsigned char *b = (unsigned char *)P->d_blob;
     smx::DevPanel &h = P->hp;
     h.ppeq = (const unsigned long long *)(b + P->o_ppeq);
@@ -303,6 +329,13 @@ static int ensure_device(smx_panel *P) {
     }
     size_t per_cu = (160 * 1024) / std::max<size_t>(P->lds, 1);
     P->blocks_per_cu = (int)std::min<size_t>(std::max<size_t>(per_cu, 1), 8);
+    if (const char *e = getenv("SMX_BLOCKS_PER_CU")) P->blocks_per_cu = std::max(1, atoi(e));
+    if (getenv("SMX_PHASE_TIMING")) {
+        P->phase_grid = P->n_cu * P->blocks_per_cu;
+        HIP_TRY(hipMalloc((void **)&P->d_phase, (size_t)P->phase_grid * 16 * 8));
+        HIP_TRY(hipMemset(P->d_phase, 0, (size_t)P->phase_grid * 16 * 8));
+        h.dbg_phase = P->d_phase;
+    }
     return SMX_OK;
 }
 
@@ -319,7 +352,7 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     uint32_t tiles = (n_reads + P->R - 1) / P->R;
     int grid = (int)std::min<uint32_t>(tiles, (uint32_t)(P->n_cu * P->blocks_per_cu));
     int e = smx_launch_demux(&P->hp, P->use64, P->R, grid, P->lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
-                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist);
+                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, P->d_tile_counter);
     if (e != 0) return fail(SMX_ERR_DEVICE, "demux kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return SMX_OK;
 }

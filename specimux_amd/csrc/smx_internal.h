@@ -14,6 +14,7 @@ static const char kCodeChars[16] = {'A', 'C', 'G', 'T', 'N', 'R', 'Y', 'K', 'M',
 // All pointers are DEVICE pointers (one allocation, see smx_api.cpp).  Passed to kernels by value.
 struct DevPanel {
     int NP, NB, NS, NPAIR;
+    int n_pbc;        // total length of the per-primer barcode lists
     int S;            // search_len
     int wstride;      // bytes per read in the window buffer
     int kidx;         // max_dist_index
@@ -34,6 +35,7 @@ struct DevPanel {
     const int *spec_next;                 // chain in file order
     const unsigned long long *spec_p1m, *spec_p2m;
     const int *spec_pool;
+    unsigned long long *dbg_phase;        // SMX_PHASE_TIMING=1: [grid][16] cycle sums per phase (diagnostic build-in)
 };
 
 }  // namespace smx
@@ -41,8 +43,9 @@ struct DevPanel {
 extern "C" {
 int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t lds_bytes, void *stream,
                      const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops, smx_op *d_extra,
-                     uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts, smx_hit *d_hits, int8_t *d_bdist);
-size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts);
+                     uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts, smx_hit *d_hits, int8_t *d_bdist,
+                     unsigned *d_tile_counter);
+size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta);
 int smx_set_demux_lds_limit(int use64, size_t bytes);
 int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,
                      const unsigned char *d_tcodes, int n, int k, int mode, int *d_dist, unsigned char *d_endflag,

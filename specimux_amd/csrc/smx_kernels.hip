@@ -97,35 +97,70 @@ static_assert(sizeof(HitL) == 24, "HitL layout");
 #define SMX_MAX_EMIT 16
 
 struct TileLayout {   // byte offsets into dynamic LDS
-    int ppeq, prpeq, bpeq, lut, codes, lens, ocnt, hits, masks, bres, offs, emit, aggr, total;
+    int ppeq, prpeq, bpeq, lut, pmeta, codes, lens, ocnt, hits, masks, tiem, bres, ents, offsA, offsB, queue, emit, opsL, aggr,
+        total;
+    int CS;      // bytes per code row (odd number of dwords: conflict-free column reads across rows)
+    int NPs, NBs;  // odd strides of the transposed Peq tables: entry [code][pattern]
+    int G, logG;   // barcode slots per (hit) group: power of two >= maxB
+    int MBW;     // tie-mask words per hit
+    int CAPH, CAPE;  // hits / (hit, location) entries processed per barcode round
 };
 
+struct EntL {   // one optimal primer location of one searched hit = one barcode target
+    unsigned short hit;     // r * H + h
+    unsigned short slot;    // first bres slot of the hit in this round
+    unsigned char tj0;      // window position of the first target base
+    unsigned char loc_ord;  // ordinal of the location (ascending end)
+    unsigned char ncol;     // target columns available (capped)
+    unsigned char ok;       // 0: target empty or rejected by the prefilter rule
+};
+static_assert(sizeof(EntL) == 8, "EntL layout");
+
 template <typename PW>
-__host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, int maxB, int need_starts) {
+__host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, int maxB, int need_starts,
+                                                    int npmeta) {
     TileLayout t;
     int H = 2 * NP, MW = (S + 31) / 32;
+    t.CS = 4 * (((S + 3) / 4) | 1);
+    t.NPs = NP | 1;
+    t.NBs = NB | 1;
+    t.G = 1; t.logG = 0;
+    while (t.G < maxB) { t.G <<= 1; t.logG++; }
+    t.MBW = (maxB + 31) / 32;
+    // barcode rounds: all hits of the tile at once when that costs <= 16 KiB of slots, else 16 KiB worth
+    int dense = R * H;
+    int fit = (16 * 1024) / (t.G * 4);
+    t.CAPH = dense < fit ? dense : (fit < 1 ? 1 : fit);
+    t.CAPE = 2 * t.CAPH < 320 ? 320 : 2 * t.CAPH;   // >= 256 = max locations of one hit (progress guarantee)
     int o = 0;
-    t.ppeq = o;  o += NP * 16 * (int)sizeof(PW);
-    t.prpeq = o; o += (need_starts ? NP * 16 * (int)sizeof(PW) : 0);
-    t.bpeq = o;  o += NB * 16 * 4;
+    t.ppeq = o;  o += t.NPs * 16 * (int)sizeof(PW);
+    t.prpeq = o; o += (need_starts ? t.NPs * 16 * (int)sizeof(PW) : 0);
+    t.bpeq = o;  o += t.NBs * 16 * 4;
     t.lut = o;   o += 512;
-    t.codes = o; o += R * 2 * S; o = (o + 15) & ~15;
+    t.pmeta = o; o += npmeta * 4;
+    o = (o + 15) & ~15;
+    t.codes = o; o += R * 2 * t.CS;
     t.lens = o;  o += R * 4;
     t.ocnt = o;  o += R * 2 * 4;
     t.hits = o;  o += R * H * (int)sizeof(HitL);
     t.masks = o; o += R * H * MW * 4;
-    t.bres = o;  o += R * H * maxB * 4;
-    t.offs = o;  o += (R * H + 1) * 4;
+    t.tiem = o;  o += R * H * t.MBW * 4;
+    t.bres = o;  o += t.CAPH * t.G * 4;
+    t.ents = o;  o += t.CAPE * (int)sizeof(EntL);
+    t.offsA = o; o += (R * H + 1) * 4;
+    t.offsB = o; o += (R * H + 1) * 4;
+    t.queue = o; o += ((R * H + 1) & ~1) * 2;
     t.emit = o;  o += R * SMX_MAX_EMIT * 4;
-    t.aggr = o;  o += 8 * 4;
+    o = (o + 15) & ~15;
+    t.opsL = o;  o += R * 32;
+    t.aggr = o;  o += 12 * 4;
     t.total = (o + 15) & ~15;
     return t;
 }
 
-// exclusive scan of a[0..n) in LDS by wave 0 (n <= 64*chunk); a[n] = total.  Caller barriers around it.
-__device__ inline void wave0_exclusive_scan(int *a, int n) {
-    int lane = threadIdx.x;
-    if (lane >= 64) return;
+// exclusive scan of a[0..n) in LDS by ONE wave (all 64 lanes of it call this); a[n] = total.
+__device__ inline void wave_exclusive_scan(int *a, int n) {
+    int lane = threadIdx.x & 63;
     int chunk = (n + 63) / 64;
     int lo = lane * chunk, hi = lo + chunk < n ? lo + chunk : n;
     int sum = 0;
@@ -140,12 +175,35 @@ __device__ inline void wave0_exclusive_scan(int *a, int n) {
     if (lane == 63) a[n] = incl;
 }
 
+// loc_ord-th (0-based) optimal end at or after jstar in a location bitmask
+__device__ __forceinline__ int nth_location(const unsigned *mrow, int MW, int jstar, int loc_ord) {
+    int seen = 0;
+    for (int w = jstar >> 5; w < MW; w++) {
+        unsigned word = mrow[w];
+        if (w == (jstar >> 5)) word &= ~0u << (jstar & 31);
+        int pc = __popc(word);
+        if (seen + pc > loc_ord) {
+            for (int t = loc_ord - seen; t > 0; t--) word &= word - 1;
+            return w * 32 + __ffs(word) - 1;
+        }
+        seen += pc;
+    }
+    return -1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Scorer helpers (phase 4).  Everything is indexed, nothing is string keyed.
+// Small per-panel tables staged in LDS (the scorer and the barcode scan read them constantly).
+struct LPanel {
+    const int *pm, *pk, *pdir, *pfidx, *pbc_off, *pbc, *bm, *pair_f, *pair_r, *pair_pool;
+};
+
 struct ReadCtx {
     const DevPanel *P;
+    LPanel LP;
     const HitL *hits;          // this read's H records
-    const unsigned *bres;      // this read's H*maxB packed results
+    const unsigned *tiem;      // this read's H*MBW tie bitmasks (barcodes at the best distance)
+    int MBW;
     int L, S;
     EndGeom g;
 };
@@ -159,8 +217,8 @@ struct CandView {
 
 __device__ __forceinline__ CandView cand_view(const ReadCtx &c, int pair, int o) {
     CandView v;
-    v.f = c.P->pair_f[pair];
-    v.r = c.P->pair_r[pair];
+    v.f = c.LP.pair_f[pair];
+    v.r = c.LP.pair_r[pair];
     v.o = o;
     v.h1 = v.f * 2 + (o == 0 ? 0 : 1);   // forward primer: end A (of rs) when the read is kept as is
     v.h2 = v.r * 2 + (o == 0 ? 1 : 0);
@@ -186,23 +244,21 @@ __device__ __forceinline__ int cand_score(const CandView &v) {   // demultiplex.
     return 0;
 }
 
-// n-th (0-based) tied barcode of hit h in canonical order -> local index; -1 when exhausted.
+// next tied barcode (local index >= from) of hit h in canonical order; -1 when exhausted.
 __device__ inline int next_tied(const ReadCtx &c, int h, int from) {
-    const DevPanel *P = c.P;
     int p = h >> 1;
-    int nb = P->pbc_off[p + 1] - P->pbc_off[p];
-    unsigned best = (unsigned)c.hits[h].bbest;
-    const unsigned *br = c.bres + h * P->maxB;
+    int nb = c.LP.pbc_off[p + 1] - c.LP.pbc_off[p];
+    const unsigned *tm = c.tiem + h * c.MBW;
     for (int i = from; i < nb; i++)
-        if ((br[i] >> 24) == best) return i;
+        if ((tm[i >> 5] >> (i & 31)) & 1) return i;
     return -1;
 }
-__device__ __forceinline__ int global_bc(const DevPanel *P, int h, int local) {
-    return P->pbc[P->pbc_off[h >> 1] + local];
+__device__ __forceinline__ int global_bc(const ReadCtx &c, int h, int local) {
+    return c.LP.pbc[c.LP.pbc_off[h >> 1] + local];
 }
 __device__ inline bool tied_has_global(const ReadCtx &c, int h, int gb) {
     for (int i = next_tied(c, h, 0); i >= 0; i = next_tied(c, h, i + 1))
-        if (global_bc(c.P, h, i) == gb) return true;
+        if (global_bc(c, h, i) == gb) return true;
     return false;
 }
 
@@ -244,7 +300,7 @@ __device__ inline void cand_extent(const ReadCtx &c, const CandView &v, int cum,
 
 struct Emitter {
     const ReadCtx *c;
-    smx_op *primary;           // ops[read]
+    smx_op *primary;           // LDS staging slot of this read's first record
     smx_op *extra;
     unsigned extra_cap;
     unsigned *n_extra;
@@ -323,9 +379,9 @@ __device__ inline void emit_op(Emitter &E, const CandView *v, int cand_id, int s
 __device__ inline void emit_partial_or_unknown(Emitter &E, const CandView &v, int cand_id, int pool) {
     const ReadCtx &c = *E.c;
     if (v.b1 && !v.b2 && c.hits[v.h1].ntied == 1)
-        emit_op(E, &v, cand_id, -1, SMX_R_PARTIAL_FWD, pool, global_bc(c.P, v.h1, c.hits[v.h1].first_tied), 0);
+        emit_op(E, &v, cand_id, -1, SMX_R_PARTIAL_FWD, pool, global_bc(c, v.h1, c.hits[v.h1].first_tied), 0);
     else if (v.b2 && !v.b1 && c.hits[v.h2].ntied == 1)
-        emit_op(E, &v, cand_id, -1, SMX_R_PARTIAL_REV, pool, global_bc(c.P, v.h2, c.hits[v.h2].first_tied), 0);
+        emit_op(E, &v, cand_id, -1, SMX_R_PARTIAL_REV, pool, global_bc(c, v.h2, c.hits[v.h2].first_tied), 0);
     else
         emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, pool, -1, 0);
 }
@@ -339,25 +395,25 @@ __device__ inline void emit_partial_or_unknown(Emitter &E, const CandView &v, in
             if (!(v.p1 || v.p2)) continue;                                               \
             if (cand_score(v) != (best)) continue;                                       \
             int cand_id = _pair * 2 + _o;                                                \
-            int cand_pool = (c).P->pair_pool[_pair];                                     \
+            int cand_pool = (c).LP.pair_pool[_pair];                                     \
             (void)cand_id; (void)cand_pool;                                              \
             __VA_ARGS__                                                                  \
         }
 
 // key for dereplicate_matches' specimen groups (demultiplex.py:371-378); all lexicographic, small ints
-__device__ __forceinline__ int key_full(const DevPanel *P, const CandView &v) {
-    return ((v.b1d + v.b2d) << 20) | ((v.p1d + v.p2d) << 12) | (P->pfidx[v.f] + P->pfidx[v.r]);
+__device__ __forceinline__ int key_full(const LPanel &P, const CandView &v) {
+    return ((v.b1d + v.b2d) << 20) | ((v.p1d + v.p2d) << 12) | (P.pfidx[v.f] + P.pfidx[v.r]);
 }
-__device__ __forceinline__ int key_partial(const DevPanel *P, const CandView &v, bool fwd) {   // :442-463
+__device__ __forceinline__ int key_partial(const LPanel &P, const CandView &v, bool fwd) {   // :442-463
     int cnt = (v.p1 ? 1 : 0) + (v.p2 ? 1 : 0);
     int pd = (v.p1 ? v.p1d : 0) + (v.p2 ? v.p2d : 0);
-    int fi = (v.p1 ? P->pfidx[v.f] : 0) + (v.p2 ? P->pfidx[v.r] : 0);
+    int fi = (v.p1 ? P.pfidx[v.f] : 0) + (v.p2 ? P.pfidx[v.r] : 0);
     return ((fwd ? v.b1d : v.b2d) << 24) | ((2 - cnt) << 22) | (pd << 12) | fi;
 }
-__device__ __forceinline__ int key_unknown(const DevPanel *P, const CandView &v) {             // :502-528
+__device__ __forceinline__ int key_unknown(const LPanel &P, const CandView &v) {             // :502-528
     int cnt = (v.p1 ? 1 : 0) + (v.p2 ? 1 : 0);
     int pd = (v.p1 ? v.p1d : 0) + (v.p2 ? v.p2d : 0);
-    int fi = (v.p1 ? P->pfidx[v.f] : 999) + (v.p2 ? P->pfidx[v.r] : 999);
+    int fi = (v.p1 ? P.pfidx[v.f] : 999) + (v.p2 ? P.pfidx[v.r] : 999);
     return ((2 - cnt) << 22) | (pd << 12) | fi;
 }
 
@@ -365,7 +421,7 @@ __device__ __forceinline__ int key_unknown(const DevPanel *P, const CandView &v)
 __device__ inline bool cand_has_specimen(const ReadCtx &c, const CandView &v, int spec) {
     for (int i = next_tied(c, v.h1, 0); i >= 0; i = next_tied(c, v.h1, i + 1))
         for (int j = next_tied(c, v.h2, 0); j >= 0; j = next_tied(c, v.h2, j + 1)) {
-            int s = specimen_exact(c.P, global_bc(c.P, v.h1, i), global_bc(c.P, v.h2, j), v.f, v.r);
+            int s = specimen_exact(c.P, global_bc(c, v.h1, i), global_bc(c, v.h2, j), v.f, v.r);
             if (s >= 0 && (spec < 0 || s == spec)) return true;
         }
     return false;
@@ -387,13 +443,44 @@ __device__ inline void score_read(Emitter &E, int ori) {
         emit_op(E, nullptr, 0, -1, SMX_R_UNKNOWN, -1, -1, 0);
         return;
     }
+    // ---- fast path: exactly one candidate carries the best score and no barcode tie is involved.  Every
+    // dereplication group then has one member, so the general machinery below reduces to a single emission.
+    {
+        int nbest = 0, only_pair = 0, only_o = 0;
+        for (int pair = 0; pair < P->NPAIR; pair++)
+            for (int o = 0; o < 2; o++) {
+                if ((o == 0 && ori == 2) || (o == 1 && ori == 1)) continue;
+                CandView v = cand_view(c, pair, o);
+                if (cand_score(v) == best) { if (nbest == 0) { only_pair = pair; only_o = o; } nbest++; }
+            }
+        if (nbest == 1) {
+            CandView v = cand_view(c, only_pair, only_o);
+            int cand_id = only_pair * 2 + only_o, cand_pool = c.LP.pair_pool[only_pair];
+            bool t1 = !v.b1 || c.hits[v.h1].ntied == 1, t2 = !v.b2 || c.hits[v.h2].ntied == 1;
+            if (best <= 2) {   // dereplicate_unknown_matches / resolve_specimen: UNKNOWN either way
+                emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, cand_pool, -1, 0);
+                return;
+            }
+            if (best <= 4 && t1 && t2) {   // one (direction, barcode) group
+                emit_partial_or_unknown(E, v, cand_id, cand_pool);
+                return;
+            }
+            if (best == 5 && t1 && t2 && P->derep == SMX_DEREP_BEST) {
+                int spec = specimen_exact(P, global_bc(c, v.h1, c.hits[v.h1].first_tied),
+                                          global_bc(c, v.h2, c.hits[v.h2].first_tied), v.f, v.r);
+                if (spec >= 0) emit_op(E, &v, cand_id, spec, SMX_R_DEREP_FULL, P->spec_pool[spec], -1, 0);
+                else emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, cand_pool, -1, SMX_OPF_NO_SPECIMEN);
+                return;
+            }
+        }
+    }
     if (P->derep == SMX_DEREP_NONE) {   // demultiplex.py:181-197
         FOR_BEST_CANDS(c, ori, best, {
             if (best == 5) {   // resolve_specimen full branch (:555-575): specimens_for_barcodes_and_primers
                 int first = -1, cnt = 0;
                 for (int i = next_tied(c, v.h1, 0); i >= 0; i = next_tied(c, v.h1, i + 1))
                     for (int j = next_tied(c, v.h2, 0); j >= 0; j = next_tied(c, v.h2, j + 1)) {
-                        int g1 = global_bc(P, v.h1, i), g2 = global_bc(P, v.h2, j);
+                        int g1 = global_bc(c, v.h1, i), g2 = global_bc(c, v.h2, j);
                         for (int s = P->pairhead[g1 * P->NB + g2]; s >= 0; s = P->spec_next[s])
                             if (((P->spec_p1m[s] >> v.f) & 1) && ((P->spec_p2m[s] >> v.r) & 1)) {
                                 cnt++;
@@ -418,7 +505,7 @@ __device__ inline void score_read(Emitter &E, int ori) {
             bool any = false;
             for (int i = next_tied(c, v.h1, 0); i >= 0; i = next_tied(c, v.h1, i + 1))
                 for (int j = next_tied(c, v.h2, 0); j >= 0; j = next_tied(c, v.h2, j + 1)) {
-                    int spec = specimen_exact(P, global_bc(P, v.h1, i), global_bc(P, v.h2, j), v.f, v.r);
+                    int spec = specimen_exact(P, global_bc(c, v.h1, i), global_bc(c, v.h2, j), v.f, v.r);
                     if (spec < 0) continue;
                     any = true;
                     // first appearance of this specimen? (earlier candidate, or earlier combo of this one)
@@ -431,7 +518,7 @@ __device__ inline void score_read(Emitter &E, int ori) {
                             for (int i2 = next_tied(c, v.h1, 0); i2 >= 0 && !seen; i2 = next_tied(c, v.h1, i2 + 1))
                                 for (int j2 = next_tied(c, v.h2, 0); j2 >= 0; j2 = next_tied(c, v.h2, j2 + 1)) {
                                     if (i2 > ci || (i2 == ci && j2 >= cj)) break;
-                                    if (specimen_exact(P, global_bc(P, v.h1, i2), global_bc(P, v.h2, j2), v.f, v.r) == spec) { seen = true; break; }
+                                    if (specimen_exact(P, global_bc(c, v.h1, i2), global_bc(c, v.h2, j2), v.f, v.r) == spec) { seen = true; break; }
                                 }
                         })
                     }
@@ -439,7 +526,7 @@ __device__ inline void score_read(Emitter &E, int ori) {
                     // the group's winner: stable min of (b1d+b2d, p1d+p2d, file index sum) over its entries
                     int wkey = 0x7FFFFFFF, wid = -1;
                     FOR_BEST_CANDS(c, ori, best, {
-                        int k = key_full(P, v);
+                        int k = key_full(c.LP, v);
                         if (k < wkey && cand_has_specimen(c, v, spec)) { wkey = k; wid = cand_id; }
                     })
                     CandView w = cand_view(c, wid >> 1, wid & 1);
@@ -465,7 +552,7 @@ __device__ inline void score_read(Emitter &E, int ori) {
             bool fwd = v.b1;
             int h = fwd ? v.h1 : v.h2;
             for (int i = next_tied(c, h, 0); i >= 0; i = next_tied(c, h, i + 1)) {
-                int gb = global_bc(P, h, i);
+                int gb = global_bc(c, h, i);
                 const int cur_id = cand_id;
                 bool seen = false;
                 int wkey = 0x7FFFFFFF, wid = -1;
@@ -474,12 +561,12 @@ __device__ inline void score_read(Emitter &E, int ori) {
                     int h2 = fwd ? v.h1 : v.h2;
                     if (!tied_has_global(c, h2, gb)) continue;
                     if (cand_id < cur_id) seen = true;
-                    int k = key_partial(P, v, fwd);
+                    int k = key_partial(c.LP, v, fwd);
                     if (k < wkey) { wkey = k; wid = cand_id; }
                 })
                 if (seen) continue;
                 CandView w = cand_view(c, wid >> 1, wid & 1);
-                emit_partial_or_unknown(E, w, wid, P->pair_pool[wid >> 1]);
+                emit_partial_or_unknown(E, w, wid, c.LP.pair_pool[wid >> 1]);
             }
         })
         return;
@@ -488,11 +575,11 @@ __device__ inline void score_read(Emitter &E, int ori) {
     {
         int wkey = 0x7FFFFFFF, wid = -1;
         FOR_BEST_CANDS(c, ori, best, {
-            int k = key_unknown(P, v);
+            int k = key_unknown(c.LP, v);
             if (k < wkey) { wkey = k; wid = cand_id; }
         })
         CandView w = cand_view(c, wid >> 1, wid & 1);
-        emit_op(E, &w, wid, -1, SMX_R_UNKNOWN, P->pair_pool[wid >> 1], -1, 0);
+        emit_op(E, &w, wid, -1, SMX_R_UNKNOWN, c.LP.pair_pool[wid >> 1], -1, 0);
     }
 }
 
@@ -502,41 +589,82 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
-                                                    unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist) {
+                                                    unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist,
+                                                    unsigned *tile_counter) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
     const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
-    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts);
-    PW *ppeq = (PW *)(lds + T.ppeq);
+    const int n_pbc = P->n_pbc, NPAIR = P->NPAIR;
+    const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
+    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta);
+    PW *ppeq = (PW *)(lds + T.ppeq);        // [code][primer], stride NPs
     PW *prpeq = (PW *)(lds + T.prpeq);
-    unsigned *bpeq = (unsigned *)(lds + T.bpeq);
+    unsigned *bpeq = (unsigned *)(lds + T.bpeq);   // [code][barcode], stride NBs
     unsigned char *lut = lds + T.lut;
     unsigned char *codes = lds + T.codes;
     int *lensL = (int *)(lds + T.lens);
     int *ocnt = (int *)(lds + T.ocnt);
     HitL *hits = (HitL *)(lds + T.hits);
     unsigned *masks = (unsigned *)(lds + T.masks);
+    unsigned *tiem = (unsigned *)(lds + T.tiem);
     unsigned *bres = (unsigned *)(lds + T.bres);
-    int *offs = (int *)(lds + T.offs);
+    EntL *ents = (EntL *)(lds + T.ents);
+    int *offsA = (int *)(lds + T.offsA);    // exclusive scan of searched locations per hit
+    int *offsB = (int *)(lds + T.offsB);    // exclusive scan of searched hits (rank)
+    unsigned short *queue = (unsigned short *)(lds + T.queue);   // rank -> hit
     unsigned *emitlog = (unsigned *)(lds + T.emit);
-    int *aggr = (int *)(lds + T.aggr);
-    const int tid = threadIdx.x;
+    smx_op *opsL = (smx_op *)(lds + T.opsL);
+    int *aggr = (int *)(lds + T.aggr);      // [0..7] counters, [8] round end rank
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int CS = T.CS, NPs = T.NPs, NBs = T.NBs, G = T.G, logG = T.logG, MBW = T.MBW;
 
-    // ---- phase 0: stage the panel
+    // ---- phase 0: stage the panel (transposed: consecutive lanes = consecutive patterns hit distinct banks)
     for (int i = tid; i < NP * 16; i += 256) {
-        ppeq[i] = (PW)P->ppeq[i];
-        if (P->need_starts) prpeq[i] = (PW)P->prpeq[i];
+        int p = i >> 4, c = i & 15;
+        ppeq[c * NPs + p] = (PW)P->ppeq[i];
+        if (P->need_starts) prpeq[c * NPs + p] = (PW)P->prpeq[i];
     }
-    for (int i = tid; i < NB * 16; i += 256) bpeq[i] = P->bpeq[i];
+    for (int i = tid; i < NB * 16; i += 256) bpeq[(i & 15) * NBs + (i >> 4)] = P->bpeq[i];
     for (int i = tid; i < 512; i += 256) lut[i] = P->lut[i];
-    if (tid < 8) aggr[tid] = 0;
+    int *pmeta = (int *)(lds + T.pmeta);
+    LPanel LP;
+    {
+        int *q = pmeta;
+        LP.pm = q; q += NP; LP.pk = q; q += NP; LP.pdir = q; q += NP; LP.pfidx = q; q += NP;
+        LP.pbc_off = q; q += NP + 1; LP.pbc = q; q += n_pbc; LP.bm = q; q += NB;
+        LP.pair_f = q; q += NPAIR; LP.pair_r = q; q += NPAIR; LP.pair_pool = q;
+        for (int i = tid; i < NP; i += 256) {
+            pmeta[i] = P->pm[i]; pmeta[NP + i] = P->pk[i]; pmeta[2 * NP + i] = P->pdir[i]; pmeta[3 * NP + i] = P->pfidx[i];
+        }
+        for (int i = tid; i <= NP; i += 256) pmeta[4 * NP + i] = P->pbc_off[i];
+        for (int i = tid; i < n_pbc; i += 256) pmeta[5 * NP + 1 + i] = P->pbc[i];
+        for (int i = tid; i < NB; i += 256) pmeta[5 * NP + 1 + n_pbc + i] = P->bm[i];
+        for (int i = tid; i < NPAIR; i += 256) {
+            int *b = pmeta + 5 * NP + 1 + n_pbc + NB;
+            b[i] = P->pair_f[i]; b[NPAIR + i] = P->pair_r[i]; b[2 * NPAIR + i] = P->pair_pool[i];
+        }
+    }
+    if (tid < 12) aggr[tid] = 0;
     __syncthreads();
 
     const int stride = P->wstride;
+    const int kidx = P->kidx, pfmin = P->pfmin;
     const uint32_t n_tiles = (n_reads + R - 1) / R;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // diagnostic phase timing (SMX_PHASE_TIMING=1): thread 0 accumulates s_memtime deltas per phase
+    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool timing = P->dbg_phase != nullptr && tid == 0;
+#define STAMP(i) do { if (timing) { unsigned long long _t = clock64(); tacc[i] += _t - tprev; tprev = _t; } } while (0)
+    // dynamic tile queue: workgroups pull tiles from a global counter (zeroed on the stream before the
+    // launch), so the tail is one tile long whatever the residency turns out to be
+    for (;;) {
+        if (tid == 0) aggr[9] = (int)atomicAdd(tile_counter, 1u);
+        __syncthreads();
+        const uint32_t tile = (uint32_t)aggr[9];
+        if (tile >= n_tiles) break;
         const uint32_t r0 = tile * R;
         const int nr = (int)((n_reads - r0) < (uint32_t)R ? (n_reads - r0) : (uint32_t)R);
+        const int nh = nr * H;
+        if (timing) tprev = clock64();
 
         // ---- phase 1: windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
         if (tid < nr) { lensL[tid] = lens[r0 + tid]; ocnt[2 * tid] = 0; ocnt[2 * tid + 1] = 0; }
@@ -550,43 +678,66 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
                 int L = lensL[r];
                 int Sp = L < S ? L : S;
                 unsigned w[4] = {v.x, v.y, v.z, v.w};
+                unsigned char *rowA = codes + (r * 2 + 0) * CS, *rowB = codes + (r * 2 + 1) * CS;
 #pragma unroll
                 for (int b = 0; b < 16; b++) {
                     int pos = cpos + b;
                     unsigned ch = (w[b >> 2] >> ((b & 3) * 8)) & 0xFF;
                     if (pos < S) {            // head byte i -> A[Sp-1-i] = code(complement)
-                        if (pos < Sp) codes[(r * 2 + 0) * S + (Sp - 1 - pos)] = lut[256 + ch];
+                        if (pos < Sp) rowA[Sp - 1 - pos] = lut[256 + ch];
                     } else if (pos < 2 * S) { // tail byte j -> B[j]
                         int j = pos - S;
-                        if (j < Sp) codes[(r * 2 + 1) * S + j] = lut[ch];
+                        if (j < Sp) rowB[j] = lut[ch];
                     }
                 }
             }
         }
         __syncthreads();
+        STAMP(0);
 
         // ---- phase 2: primer scan, one lane per (read, primer, end)
-        for (int item = tid; item < nr * H; item += 256) {
+        for (int item = tid; item < nh; item += 256) {
             int r = item / H, h = item - r * H, p = h >> 1, X = h & 1;
             int L = lensL[r];
             EndGeom g = end_geom(L, S);
-            const unsigned char *cw = codes + (r * 2 + X) * S;
-            const PW *peq = ppeq + p * 16;
-            const int m = P->pm[p], k = P->pk[p], top = m - 1;
+            const unsigned char *cw = codes + (r * 2 + X) * CS;
+            const PW *peq = ppeq + p;
+            const int m = LP.pm[p], k = LP.pk[p], top = m - 1;
             PW Pvv = ~(PW)0, Mv = 0;
             int score = m, best = m + 1, jstar = 0, cnt = 0;
-            unsigned *mrow = masks + (size_t)(r * H + h) * MW;
-            for (int w = 0; w < MW; w++) {
-                unsigned word = 0;
-                int jend = (w + 1) * 32 < S ? (w + 1) * 32 : S;
-                for (int j = w * 32; j < jend; j++) {
-                    if (j >= g.j_lo && j < g.Sp) {
-                        myers_step<PW, false>(peq[cw[j]], Pvv, Mv, score, top);
-                        if (score < best) { best = score; jstar = j; cnt = 0; }
-                        if (score == best) { cnt++; word |= 1u << (j & 31); }
+            unsigned *mrow = masks + (size_t)item * MW;
+            if (g.j_lo == 0) {
+                // common case: the target is the whole stored window; branch-free bookkeeping per column
+                const int Sp = g.Sp;
+                for (int w = 0; w < MW; w++) {
+                    unsigned word = 0;
+                    int jend = (w + 1) * 32 < Sp ? (w + 1) * 32 : Sp;
+#pragma unroll 4
+                    for (int j = w * 32; j < jend; j++) {
+                        myers_step<PW, false>(peq[cw[j] * NPs], Pvv, Mv, score, top);
+                        bool lt = score < best;
+                        best = lt ? score : best;
+                        jstar = lt ? j : jstar;
+                        cnt = lt ? 0 : cnt;
+                        bool eqb = score == best;
+                        cnt += eqb ? 1 : 0;
+                        word |= (eqb ? 1u : 0u) << (j & 31);
                     }
+                    mrow[w] = word;
                 }
-                mrow[w] = word;
+            } else {
+                for (int w = 0; w < MW; w++) {
+                    unsigned word = 0;
+                    int jend = (w + 1) * 32 < S ? (w + 1) * 32 : S;
+                    for (int j = w * 32; j < jend; j++) {
+                        if (j >= g.j_lo && j < g.Sp) {
+                            myers_step<PW, false>(peq[cw[j] * NPs], Pvv, Mv, score, top);
+                            if (score < best) { best = score; jstar = j; cnt = 0; }
+                            if (score == best) { cnt++; word |= 1u << (j & 31); }
+                        }
+                    }
+                    mrow[w] = word;
+                }
             }
             bool matched = best <= k;
             bool omatch = matched;
@@ -594,7 +745,7 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
                 PW P2 = ~(PW)0, M2 = 0;
                 int sc = m, b2 = m + 1;
                 for (int j = 0; j < g.Sp; j++) {
-                    myers_step<PW, false>(peq[cw[j]], P2, M2, sc, top);
+                    myers_step<PW, false>(peq[cw[j] * NPs], P2, M2, sc, top);
                     b2 = sc < b2 ? sc : b2;
                 }
                 omatch = b2 <= k;
@@ -603,14 +754,14 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
             if (matched && P->need_starts) {
                 // edlib's start rule: SHW of the reversed pattern over the reversed target prefix,
                 // LAST optimal position = smallest start
-                const PW *rpeq = prpeq + p * 16;
+                const PW *rpeq = prpeq + p;
                 PW P2 = ~(PW)0, M2 = 0;
                 int sc = m, lastc = 1;
                 int maxc = m + best;
                 for (int c = 1; c <= maxc; c++) {
                     int j = jstar - (c - 1);
                     if (j < g.j_lo) break;
-                    myers_step<PW, true>(rpeq[cw[j]], P2, M2, sc, top);
+                    myers_step<PW, true>(rpeq[cw[j] * NPs], P2, M2, sc, top);
                     if (sc == best) lastc = c;
                 }
                 fs_j = jstar - (lastc - 1);
@@ -622,142 +773,188 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
             hl.bbest = -2; hl.ntied = 0; hl.first_tied = -1;
             hl.jstar = (unsigned char)jstar; hl.fs_j = (unsigned char)fs_j;
             hl.flags = (unsigned char)(omatch ? 1 : 0); hl.pad = 0;
-            hits[r * H + h] = hl;
+            hits[item] = hl;
             if (omatch) {
                 // determine_orientation via A.6: fwd primer in A / rev primer in B vote "forward"
-                int dir = P->pdir[p];
+                int dir = LP.pdir[p];
                 int vote_fwd = (dir == 0) ? (X == 0) : (X == 1);
                 atomicAdd(&ocnt[2 * r + (vote_fwd ? 0 : 1)], 1);
             }
         }
         __syncthreads();
+        STAMP(1);
 
-        // ---- phase 3a: orientation, which ends need barcodes, item counts
-        for (int item = tid; item < nr * H; item += 256) {
+        // ---- phase 3a: orientation, which ends need barcodes; scans of locations (A) and searched hits (B)
+        for (int item = tid; item < nh; item += 256) {
             int r = item / H, h = item - r * H, p = h >> 1, X = h & 1;
             int L = lensL[r];
             int f = ocnt[2 * r], rv = ocnt[2 * r + 1];
             int ori = 3;   // bit0: as-read candidates allowed, bit1: reverse-complement candidates allowed
             if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
             bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
-            int dir = P->pdir[p];
+            int dir = LP.pdir[p];
             bool in_fwd = (dir == 0) ? (X == 0) : (X == 1);   // used by as-read candidates
             bool needed = !filtered && ((in_fwd && (ori & 1)) || (!in_fwd && (ori & 2)));
-            HitL &hl = hits[r * H + h];
+            HitL &hl = hits[item];
             int n = 0;
             if (needed && hl.pdist >= 0) {
                 hl.flags |= 2;
                 hl.bbest = -1;
-                n = hl.nloc * (P->pbc_off[p + 1] - P->pbc_off[p]);
+                n = hl.nloc;
             }
-            offs[item] = n;
+            offsA[item] = n;
+            offsB[item] = n > 0 ? 1 : 0;
+            for (int w = 0; w < MBW; w++) tiem[item * MBW + w] = 0;
         }
-        for (int i = tid; i < nr * H * maxB; i += 256) bres[i] = 0xFFFFFFFFu;
+        if (dbg_bdist)
+            for (int i = tid; i < nh * maxB; i += 256) dbg_bdist[(size_t)r0 * H * maxB + i] = -1;
         __syncthreads();
-        wave0_exclusive_scan(offs, nr * H);
+        if (wave == 0) wave_exclusive_scan(offsA, nh);
+        else if (wave == 1) wave_exclusive_scan(offsB, nh);
         __syncthreads();
+        for (int item = tid; item < nh; item += 256)
+            if (offsB[item + 1] != offsB[item]) queue[offsB[item]] = (unsigned short)item;
+        const int nq = offsB[nh];
+        __syncthreads();
+        STAMP(2);
 
-        // ---- phase 3b: barcode scan, one lane per (hit, location, barcode)
-        {
-            const int total = offs[nr * H];
-            const int kidx = P->kidx, pfmin = P->pfmin;
-            for (int item = tid; item < total; item += 256) {
-                int lo = 0, hi = nr * H;    // largest hh with offs[hh] <= item
-                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (offs[mid] <= item) lo = mid; else hi = mid; }
-                int hh = lo, r = hh / H, h = hh - r * H, p = h >> 1, X = h & 1;
-                int local = item - offs[hh];
-                int nb = P->pbc_off[p + 1] - P->pbc_off[p];
-                int loc_ord = local / nb, bi = local - loc_ord * nb;
-                const HitL &hl = hits[hh];
-                // loc_ord-th optimal end (bits at or after jstar)
-                const unsigned *mrow = masks + (size_t)hh * MW;
-                int je = -1, seen = 0;
-                for (int w = hl.jstar >> 5; w < MW && je < 0; w++) {
-                    unsigned word = mrow[w];
-                    if (w == (hl.jstar >> 5)) word &= ~0u << (hl.jstar & 31);
-                    int pc = __popc(word);
-                    if (seen + pc > loc_ord) {
-                        for (int t = loc_ord - seen; t > 0; t--) word &= word - 1;
-                        je = w * 32 + __ffs(word) - 1;
+        // ---- phase 3b/3c in rounds of at most CAPH searched hits and CAPE (hit, location) entries
+        for (int q0 = 0; q0 < nq;) {
+            int q1;
+            {
+                int e_base = offsA[queue[q0]];
+                if (nq - q0 <= T.CAPH && offsA[nh] - e_base <= T.CAPE) q1 = nq;   // everything left fits (usual case)
+                else {
+                    if (tid == 0) {
+                        int q = q0 + 1;   // one hit always fits: CAPE >= 256 >= its locations
+                        while (q < nq && q - q0 < T.CAPH) {
+                            int hq = queue[q];
+                            if (offsA[hq] + hits[hq].nloc - e_base > T.CAPE) break;
+                            q++;
+                        }
+                        aggr[8] = q;
                     }
-                    seen += pc;
+                    __syncthreads();
+                    q1 = aggr[8];
                 }
+            }
+            const int e_base = offsA[queue[q0]];
+            const int e_end = (q1 < nq) ? offsA[queue[q1]] : offsA[nh];
+            const int nE = e_end - e_base;
+            // entries: one thread per searched hit of the round lists its optimal locations
+            for (int q = q0 + tid; q < q1; q += 256) {
+                int item = queue[q];
+                int r = item / H, h = item - r * H, X = h & 1;
+                const HitL &hl = hits[item];
                 int L = lensL[r];
                 EndGeom g = end_geom(L, S);
-                int bstart = (je - g.j_lo) + g.shift + 1;
-                BcGeom bg = bc_geom(L, g.base, bstart);
-                int gb = P->pbc[P->pbc_off[p] + bi];
-                int m = P->bm[gb], top = m - 1;
-                const unsigned char *cw = codes + (r * 2 + X) * S;
-                int ncol = g.Sp - bg.tj0;
-                if (ncol > m + kidx) ncol = m + kidx;
-                bool ok = ncol > 0;
-                if (ok && pfmin > 0) {   // exact-set restatement of BloomPrefilter.match (Q7)
-                    if (!bg.pf_same || g.Sp - bg.tj0 < pfmin) ok = false;
-                    else for (int c = 0; c < pfmin; c++) if (cw[bg.tj0 + c] > 3) { ok = false; break; }
+                const unsigned *mrow = masks + (size_t)item * MW;
+                const unsigned char *cw = codes + (r * 2 + X) * CS;
+                int e = offsA[item] - e_base, ord = 0;
+                for (int w = hl.jstar >> 5; w < MW; w++) {
+                    unsigned word = mrow[w];
+                    if (w == (hl.jstar >> 5)) word &= ~0u << (hl.jstar & 31);
+                    while (word) {
+                        int je = w * 32 + __ffs(word) - 1;
+                        word &= word - 1;
+                        int bstart = (je - g.j_lo) + g.shift + 1;
+                        BcGeom bg = bc_geom(L, g.base, bstart);
+                        int ncol = g.Sp - bg.tj0;
+                        bool ok = ncol > 0;
+                        if (ok && pfmin > 0) {   // exact-set restatement of BloomPrefilter.match (Q7)
+                            if (!bg.pf_same || ncol < pfmin) ok = false;
+                            else for (int c = 0; c < pfmin; c++) if (cw[bg.tj0 + c] > 3) { ok = false; break; }
+                        }
+                        EntL en;
+                        en.hit = (unsigned short)item;
+                        en.slot = (unsigned short)((q - q0) << logG);
+                        en.tj0 = (unsigned char)(ok ? bg.tj0 : 0);
+                        en.loc_ord = (unsigned char)ord;
+                        en.ncol = (unsigned char)(ncol > 255 ? 255 : (ncol < 0 ? 0 : ncol));
+                        en.ok = ok ? 1 : 0;
+                        ents[e++] = en;
+                        ord++;
+                    }
                 }
-                if (!ok) continue;
-                const unsigned *peq = bpeq + gb * 16;
+            }
+            for (int i = tid; i < ((q1 - q0) << logG); i += 256) bres[i] = 0xFFFFFFFFu;
+            __syncthreads();
+            STAMP(3);
+
+            // 3b: barcode scan, one lane per (entry, barcode slot)
+            for (int item = tid; item < (nE << logG); item += 256) {
+                const EntL en = ents[item >> logG];
+                int bi = item & (G - 1);
+                int hh = en.hit, h = hh % H, p = h >> 1, X = h & 1, r = hh / H;
+                int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
+                if (bi >= nb || !en.ok) continue;
+                int gb = LP.pbc[LP.pbc_off[p] + bi];
+                int m = LP.bm[gb], top = m - 1;
+                const unsigned char *cw = codes + (r * 2 + X) * CS + en.tj0;
+                int ncol = en.ncol < m + kidx ? en.ncol : m + kidx;
+                const unsigned *peq = bpeq + gb;
                 unsigned Pvv = ~0u, Mv = 0;
                 int score = m, best = m + 1, firstc = 0, lastc = 0;
+#pragma unroll 4
                 for (int c = 0; c < ncol; c++) {
-                    myers_step<unsigned, true>(peq[cw[bg.tj0 + c]], Pvv, Mv, score, top);
-                    if (score < best) { best = score; firstc = c; }
-                    if (score == best) lastc = c;
+                    myers_step<unsigned, true>(peq[cw[c] * NBs], Pvv, Mv, score, top);
+                    bool lt = score < best;
+                    best = lt ? score : best;
+                    firstc = lt ? c : firstc;
+                    lastc = (score == best) ? c : lastc;
                 }
                 if (best <= kidx)
-                    atomicMin(&bres[hh * maxB + bi], ((unsigned)best << 24) | ((unsigned)loc_ord << 16) |
-                                                         ((unsigned)(bg.tj0 + firstc) << 8) | (unsigned)(bg.tj0 + lastc));
+                    atomicMin(&bres[en.slot + bi], ((unsigned)best << 24) | ((unsigned)en.loc_ord << 16) |
+                                                       ((unsigned)(en.tj0 + firstc) << 8) | (unsigned)(en.tj0 + lastc));
             }
-        }
-        __syncthreads();
+            __syncthreads();
+            STAMP(4);
 
-        // ---- phase 3c: per hit summary (best distance, tie set size, tails extent)
-        for (int item = tid; item < nr * H; item += 256) {
-            HitL &hl = hits[item];
-            if (!(hl.flags & 2)) continue;
-            int r = item / H, h = item - r * H, p = h >> 1;
-            int nb = P->pbc_off[p + 1] - P->pbc_off[p];
-            const unsigned *br = bres + item * maxB;
-            unsigned best = 255;
-            for (int i = 0; i < nb; i++) { unsigned d = br[i] >> 24; best = d < best ? d : best; }
-            if (best == 255) continue;
-            int L = lensL[r];
-            EndGeom g = end_geom(L, S);
-            int ntied = 0, first = -1, tail = -0x7FFFFFFF, bfirst = -1;
-            for (int i = 0; i < nb; i++) {
-                unsigned v = br[i];
-                if (v == 0xFFFFFFFFu) continue;
-                int delta = 0;
-                if (L < S) {   // short read: the location's slice start may have wrapped (Q1)
-                    int loc_ord = (v >> 16) & 0xFF;
-                    const unsigned *mrow = masks + (size_t)item * MW;
-                    int je = -1, seen = 0;
-                    for (int w = hl.jstar >> 5; w < MW && je < 0; w++) {
-                        unsigned word = mrow[w];
-                        if (w == (hl.jstar >> 5)) word &= ~0u << (hl.jstar & 31);
-                        int pc = __popc(word);
-                        if (seen + pc > loc_ord) {
-                            for (int t = loc_ord - seen; t > 0; t--) word &= word - 1;
-                            je = w * 32 + __ffs(word) - 1;
-                        }
-                        seen += pc;
+            // 3c: per searched hit: best distance, tie set, tails extent
+            for (int q = q0 + tid; q < q1; q += 256) {
+                int item = queue[q];
+                HitL &hl = hits[item];
+                int r = item / H, h = item - r * H, p = h >> 1;
+                int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
+                const unsigned *br = bres + ((q - q0) << logG);
+                unsigned best = 255;
+                for (int i = 0; i < nb; i++) { unsigned d = br[i] >> 24; best = d < best ? d : best; }
+                if (dbg_bdist)
+                    for (int i = 0; i < nb; i++)
+                        dbg_bdist[(size_t)r0 * H * maxB + (size_t)item * maxB + i] =
+                            (br[i] == 0xFFFFFFFFu) ? (int8_t)-1 : (int8_t)(br[i] >> 24);
+                if (best == 255) continue;
+                int L = lensL[r];
+                EndGeom g = end_geom(L, S);
+                int ntied = 0, first = -1, tail = -0x7FFFFFFF, bfirst = -1;
+                for (int i = 0; i < nb; i++) {
+                    unsigned v = br[i];
+                    if (v == 0xFFFFFFFFu) continue;
+                    int delta = 0;
+                    if (L < S) {   // short read: the location's slice start may have wrapped (Q1)
+                        int je = nth_location(masks + (size_t)item * MW, MW, hl.jstar, (v >> 16) & 0xFF);
+                        delta = bc_geom(L, g.base, (je - g.j_lo) + g.shift + 1).delta;
                     }
-                    delta = bc_geom(L, g.base, (je - g.j_lo) + g.shift + 1).delta;
+                    int last_abs = (int)(v & 0xFF) + g.base - delta;
+                    int first_abs = (int)((v >> 8) & 0xFF) + g.base - delta;
+                    tail = last_abs > tail ? last_abs : tail;
+                    if ((v >> 24) == best) {
+                        if (ntied == 0) { first = i; bfirst = first_abs; }
+                        ntied++;
+                        tiem[item * MBW + (i >> 5)] |= 1u << (i & 31);
+                    }
                 }
-                int last_abs = (int)(v & 0xFF) + g.base - delta;
-                int first_abs = (int)((v >> 8) & 0xFF) + g.base - delta;
-                tail = last_abs > tail ? last_abs : tail;
-                if ((v >> 24) == best) { if (ntied == 0) { first = i; bfirst = first_abs; } ntied++; }
+                hl.bbest = (short)best; hl.ntied = (short)ntied; hl.first_tied = (short)first;
+                hl.tail_end = tail; hl.bfirst_end = bfirst;
             }
-            hl.bbest = (short)best; hl.ntied = (short)ntied; hl.first_tied = (short)first;
-            hl.tail_end = tail; hl.bfirst_end = bfirst;
+            __syncthreads();
+            STAMP(5);
+            q0 = q1;
         }
-        __syncthreads();
 
         // ---- phase 4: scorer, one lane per read (reads spread over the 4 waves)
         {
-            int r = (tid & 63) * 4 + (tid >> 6);
+            int r = tid;   // reads packed into the lowest waves: the other waves just wait at the barrier
             if (r < nr) {
                 int L = lensL[r];
                 bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
@@ -768,28 +965,37 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
                     op.sample = -1; op.trim_start = 0; op.trim_end = 0; op.pool = -1; op.p1 = op.p2 = -1; op.barcode = -1;
                     op.dist[0] = op.dist[1] = op.dist[2] = op.dist[3] = -1;
                     op.rtype = SMX_R_FILTERED; op.flags = 0; op.n_ops = 0; op.read = r0 + r;
-                    ops[r0 + r] = op;
+                    opsL[r] = op;
                 } else {
                     ReadCtx c;
-                    c.P = P; c.hits = hits + r * H; c.bres = bres + r * H * maxB; c.L = L; c.S = S; c.g = end_geom(L, S);
+                    c.P = P; c.LP = LP; c.hits = hits + r * H; c.tiem = tiem + r * H * MBW; c.MBW = MBW; c.L = L; c.S = S;
+                    c.g = end_geom(L, S);
                     int f = ocnt[2 * r], rv = ocnt[2 * r + 1];
                     int ori = 3;
                     if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
                     Emitter E;
-                    E.c = &c; E.primary = ops + r0 + r; E.extra = extra; E.extra_cap = extra_cap; E.n_extra = n_extra;
+                    E.c = &c; E.primary = opsL + r; E.extra = extra; E.extra_cap = extra_cap; E.n_extra = n_extra;
                     E.counts = counts; E.emitlog = emitlog + r * SMX_MAX_EMIT; E.aggr = aggr; E.read = r0 + r;
                     E.n = 0; E.matched = false; E.overflow = false;
                     score_read(E, ori);
-                    ops[r0 + r].n_ops = (uint16_t)E.n;
+                    opsL[r].n_ops = (uint16_t)E.n;
                     if (E.matched) atomicAdd(&aggr[1], 1);
                     if (E.n > 1) atomicAdd(&aggr[6], 1);
                     if (E.overflow) atomicAdd(&aggr[7], 1);
                 }
             }
         }
-        // ---- optional parity dumps
+        __syncthreads();
+        STAMP(6);
+        // result records: LDS -> HBM, 16 bytes per lane, fully coalesced
+        {
+            const uint4 *srcv = (const uint4 *)opsL;
+            uint4 *dstv = (uint4 *)(ops + r0);
+            for (int i = tid; i < nr * 2; i += 256) dstv[i] = srcv[i];
+        }
+        // ---- optional parity dump
         if (dbg_hits) {
-            for (int item = tid; item < nr * H; item += 256) {
+            for (int item = tid; item < nh; item += 256) {
                 int r = item / H;
                 const HitL &hl = hits[item];
                 EndGeom g = end_geom(lensL[r], S);
@@ -798,20 +1004,18 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
                 o.first_start = hl.pdist >= 0 ? (int)hl.fs_j - g.j_lo + g.shift : -1;
                 o.first_end = hl.pdist >= 0 ? (int)hl.jstar - g.j_lo + g.shift : -1;
                 o.bbest = hl.bbest; o.ntied = hl.ntied;
-                o.first_tied = (short)((hl.bbest >= 0) ? P->pbc[P->pbc_off[(item - r * H) >> 1] + hl.first_tied] : -1);
+                o.first_tied = (short)((hl.bbest >= 0) ? LP.pbc[LP.pbc_off[(item - r * H) >> 1] + hl.first_tied] : -1);
                 o.tail_end = hl.bbest >= 0 ? hl.tail_end : -1;
                 o.pad = 0;
                 dbg_hits[(size_t)(r0 + r) * H + (item - r * H)] = o;
             }
         }
-        if (dbg_bdist) {
-            for (int i = tid; i < nr * H * maxB; i += 256) {
-                unsigned v = bres[i];
-                dbg_bdist[(size_t)r0 * H * maxB + i] = (v == 0xFFFFFFFFu) ? (int8_t)-1 : (int8_t)(v >> 24);
-            }
-        }
         __syncthreads();
+        STAMP(7);
     }
+    if (timing)
+        for (int i = 0; i < 10; i++) P->dbg_phase[(size_t)blockIdx.x * 16 + i] += tacc[i];
+#undef STAMP
     // block aggregates -> global counters
     if (tid < 8 && aggr[tid]) atomicAdd(&counts[tid], (unsigned long long)aggr[tid]);
 }
@@ -855,22 +1059,24 @@ __global__ void align_kernel(const unsigned long long *peq, const unsigned long 
 extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t lds_bytes, void *stream,
                                 const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops,
                                 smx_op *d_extra, uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts,
-                                smx_hit *d_hits, int8_t *d_bdist) {
+                                smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter) {
     hipStream_t s = (hipStream_t)stream;
+    hipError_t me = hipMemsetAsync(d_tile_counter, 0, sizeof(unsigned), s);
+    if (me != hipSuccess) return (int)me;
     if (use64)
         hipLaunchKernelGGL(smx::demux_kernel<unsigned long long>, dim3(grid), dim3(256), lds_bytes, s, *P, d_windows,
                            d_lens, n_reads, R, d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts,
-                           d_hits, d_bdist);
+                           d_hits, d_bdist, d_tile_counter);
     else
         hipLaunchKernelGGL(smx::demux_kernel<unsigned>, dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens,
                            n_reads, R, d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits,
-                           d_bdist);
+                           d_bdist, d_tile_counter);
     return (int)hipGetLastError();
 }
 
-extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts) {
-    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts).total
-                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts).total;
+extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta) {
+    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta).total
+                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta).total;
 }
 
 extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {

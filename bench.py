@@ -114,7 +114,8 @@ def main():
     pan = synth.panel_c2(SEED)
     tmp = tempfile.mkdtemp(prefix="smx_bench_")
     pf, sf = pan.write(tmp)
-    rs = synth.make_reads(pan, a.reads, SEED + rank)     # this rank's shard (weak scaling)
+    from specimux_amd.distributed import shard_seed
+    rs = synth.make_reads(pan, a.reads, shard_seed(SEED, rank))     # this rank's shard (weak scaling)
 
     cpu = None
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
@@ -152,15 +153,8 @@ def main():
     d_counts = torch.zeros(cp.counts_len, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream()
 
-    comm = C.c_void_p()
-    if world > 1:   # RCCL communicator of the C ABI; the 128-byte id travels over torch.distributed
-        uid = (C.c_uint8 * 128)()
-        if rank == 0:
-            _lib.check(lib.smx_comm_unique_id(uid))
-        box = [bytes(uid)]
-        dist.broadcast_object_list(box, src=0)
-        uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
-        _lib.check(lib.smx_comm_init(uid, world, rank, C.byref(comm)))
+    from specimux_amd.distributed import CountsReducer
+    reducer = CountsReducer(world, rank, "rccl")   # RCCL communicator of the C ABI (id over torch.distributed)
 
     def step():
         d_nextra.zero_()
@@ -185,9 +179,7 @@ def main():
         s0.record(stream)
         step()
         s1.record(stream)
-    if world > 1:   # the one exchange step of the path: per-specimen counts, once per job
-        _lib.check(lib.smx_counts_allreduce(C.c_void_p(d_counts.data_ptr()), cp.counts_len, comm,
-                                            C.c_void_p(stream.cuda_stream)))
+    reducer.allreduce_(d_counts, stream.cuda_stream)   # the one exchange of the path: counts, once per job
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -201,8 +193,8 @@ def main():
     total_reads = world * n * a.steps
     assert counts[_lib.CNT_TOTAL] == total_reads, (counts[:8], total_reads)
     assert counts[_lib.CNT_OVERFLOW] == 0 and int(d_nextra[0].item()) <= extra_cap
+    reducer.close()
     if world > 1:
-        lib.smx_comm_destroy(comm)
         dist.destroy_process_group()
     if rank != 0:
         return

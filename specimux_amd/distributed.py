@@ -1,0 +1,68 @@
+"""Multi-GPU plumbing: one process per GPU, reads sharded by rank, no collective on the data path.
+
+The only exchange of the whole job is the sum of the per-rank counts vectors
+(`[total, matched, filtered, ..., per-specimen...]`, include/smx.h SMX_CNT_*) -- the analogue of the
+reference's parent process adding up `(batch_total, batch_matched)` tuples (orchestration.py:203-207).
+On GPUs it runs through the C ABI (`smx_counts_allreduce`, RCCL over xGMI); the rendezvous for the RCCL
+unique id and the CPU rehearsal (gloo) use torch.distributed."""
+import ctypes as C
+import os
+
+
+def env_rank():
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous [lo, hi) of `n_items` owned by `rank` (strong scaling over one input file)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_seed(seed: int, rank: int) -> int:
+    """Weak scaling over synthetic data: every rank generates its own shard."""
+    return seed + rank
+
+
+class CountsReducer:
+    """Sums a counts vector across ranks once per job.
+
+    backend 'rccl': device tensor, C-ABI communicator (smx_comm_* / smx_counts_allreduce);
+    backend 'torch': whatever torch.distributed backend is initialised (gloo on CPU in the tests)."""
+
+    def __init__(self, world: int, rank: int, backend: str):
+        self.world, self.rank, self.backend = world, rank, backend
+        self.comm = C.c_void_p()
+        if world > 1 and backend == "rccl":
+            import torch.distributed as dist
+            from . import _lib
+            lib = _lib.load()
+            uid = (C.c_uint8 * 128)()
+            if rank == 0:
+                _lib.check(lib.smx_comm_unique_id(uid))
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0)
+            uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            _lib.check(lib.smx_comm_init(uid, world, rank, C.byref(self.comm)))
+
+    def allreduce_(self, counts, stream_ptr=None):
+        """In-place sum of an int64/uint64 tensor over all ranks."""
+        if self.world == 1:
+            return counts
+        if self.backend == "rccl":
+            from . import _lib
+            _lib.check(_lib.load().smx_counts_allreduce(C.c_void_p(counts.data_ptr()), counts.numel(), self.comm,
+                                                        C.c_void_p(stream_ptr) if stream_ptr else None))
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        return counts
+
+    def close(self):
+        if self.comm:
+            from . import _lib
+            _lib.load().smx_comm_destroy(self.comm)
+            self.comm = C.c_void_p()

@@ -246,6 +246,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
                                           5 * NP + 1 + h.n_pbc + NB + 3 * NPAIR);
         if (need <= budget || R == 1) { P->R = R; P->lds = need; break; }
     }
+    if (const char *e = getenv("SMX_LDS_PAD")) P->lds += (size_t)atol(e);   // tuning experiment: residency vs LDS size
     if (P->lds > 160 * 1024) { delete P; return fail(SMX_ERR_UNSUPPORTED, "panel needs %zu bytes of LDS per read tile", P->lds); }
     *out = P;
     return SMX_OK;
@@ -330,6 +331,12 @@ static int ensure_device(smx_panel *P) {
     size_t per_cu = (160 * 1024) / std::max<size_t>(P->lds, 1);
     P->blocks_per_cu = (int)std::min<size_t>(std::max<size_t>(per_cu, 1), 8);
     if (const char *e = getenv("SMX_BLOCKS_PER_CU")) P->blocks_per_cu = std::max(1, atoi(e));
+    if (getenv("SMX_DEBUG")) {
+        int occ = -1;
+        (void)smx_query_occupancy(P->use64, P->lds, &occ);
+        fprintf(stderr, "[smx] R=%d lds=%zu occupancy API: %d blocks/CU, grid multiplier %d, CUs %d\n", P->R, P->lds, occ,
+                P->blocks_per_cu, P->n_cu);
+    }
     if (getenv("SMX_PHASE_TIMING")) {
         P->phase_grid = P->n_cu * P->blocks_per_cu;
         HIP_TRY(hipMalloc((void **)&P->d_phase, (size_t)P->phase_grid * 16 * 8));

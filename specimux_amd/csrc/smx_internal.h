@@ -47,6 +47,7 @@ int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t 
                      unsigned *d_tile_counter);
 size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta);
 int smx_set_demux_lds_limit(int use64, size_t bytes);
+int smx_query_occupancy(int use64, size_t lds_bytes, int *blocks_per_cu);
 int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,
                      const unsigned char *d_tcodes, int n, int k, int mode, int *d_dist, unsigned char *d_endflag,
                      int *d_starts);

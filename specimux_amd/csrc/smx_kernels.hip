@@ -100,7 +100,8 @@ struct TileLayout {   // byte offsets into dynamic LDS
     int ppeq, prpeq, bpeq, lut, pmeta, codes, lens, ocnt, hits, masks, tiem, bres, ents, offsA, offsB, queue, emit, opsL, aggr,
         total;
     int CS;      // bytes per code row (odd number of dwords: conflict-free column reads across rows)
-    int NPs, NBs;  // odd strides of the transposed Peq tables: entry [code][pattern]
+    int lNPs, lNBs;  // their log2
+    int NPs, NBs;  // power-of-two strides of the transposed Peq tables: entry [code][pattern]
     int G, logG;   // barcode slots per (hit) group: power of two >= maxB
     int MBW;     // tie-mask words per hit
     int CAPH, CAPE;  // hits / (hit, location) entries processed per barcode round
@@ -122,8 +123,8 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     TileLayout t;
     int H = 2 * NP, MW = (S + 31) / 32;
     t.CS = 4 * (((S + 3) / 4) | 1);
-    t.NPs = NP | 1;
-    t.NBs = NB | 1;
+    t.NPs = 1; t.lNPs = 0; while (t.NPs < NP) { t.NPs <<= 1; t.lNPs++; }   // table index = (code << log2) | pattern:
+    t.NBs = 1; t.lNBs = 0; while (t.NBs < NB) { t.NBs <<= 1; t.lNBs++; }   // no integer multiply in the inner loops
     t.G = 1; t.logG = 0;
     while (t.G < maxB) { t.G <<= 1; t.logG++; }
     t.MBW = (maxB + 31) / 32;
@@ -585,7 +586,7 @@ __device__ inline void score_read(Emitter &E, int ori) {
 
 // ------------------------------------------------------------------------------------------------
 template <typename PW>
-__global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
+__global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
     smx_op *opsL = (smx_op *)(lds + T.opsL);
     int *aggr = (int *)(lds + T.aggr);      // [0..7] counters, [8] round end rank
     const int tid = threadIdx.x, wave = tid >> 6;
-    const int CS = T.CS, NPs = T.NPs, NBs = T.NBs, G = T.G, logG = T.logG, MBW = T.MBW;
+    const int CS = T.CS, NPs = T.NPs, NBs = T.NBs, lNPs = T.lNPs, lNBs = T.lNBs, G = T.G, logG = T.logG, MBW = T.MBW;
 
     // ---- phase 0: stage the panel (transposed: consecutive lanes = consecutive patterns hit distinct banks)
     for (int i = tid; i < NP * 16; i += 256) {
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
                     int jend = (w + 1) * 32 < Sp ? (w + 1) * 32 : Sp;
 #pragma unroll 4
                     for (int j = w * 32; j < jend; j++) {
-                        myers_step<PW, false>(peq[cw[j] * NPs], Pvv, Mv, score, top);
+                        myers_step<PW, false>(peq[(int)cw[j] << lNPs], Pvv, Mv, score, top);
                         bool lt = score < best;
                         best = lt ? score : best;
                         jstar = lt ? j : jstar;
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
                     int jend = (w + 1) * 32 < S ? (w + 1) * 32 : S;
                     for (int j = w * 32; j < jend; j++) {
                         if (j >= g.j_lo && j < g.Sp) {
-                            myers_step<PW, false>(peq[cw[j] * NPs], Pvv, Mv, score, top);
+                            myers_step<PW, false>(peq[(int)cw[j] << lNPs], Pvv, Mv, score, top);
                             if (score < best) { best = score; jstar = j; cnt = 0; }
                             if (score == best) { cnt++; word |= 1u << (j & 31); }
                         }
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
                 PW P2 = ~(PW)0, M2 = 0;
                 int sc = m, b2 = m + 1;
                 for (int j = 0; j < g.Sp; j++) {
-                    myers_step<PW, false>(peq[cw[j] * NPs], P2, M2, sc, top);
+                    myers_step<PW, false>(peq[(int)cw[j] << lNPs], P2, M2, sc, top);
                     b2 = sc < b2 ? sc : b2;
                 }
                 omatch = b2 <= k;
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
                 for (int c = 1; c <= maxc; c++) {
                     int j = jstar - (c - 1);
                     if (j < g.j_lo) break;
-                    myers_step<PW, true>(rpeq[cw[j] * NPs], P2, M2, sc, top);
+                    myers_step<PW, true>(rpeq[(int)cw[j] << lNPs], P2, M2, sc, top);
                     if (sc == best) lastc = c;
                 }
                 fs_j = jstar - (lastc - 1);
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(256) void demux_kernel(DevPanel Pv, const uint8_t *
                 int score = m, best = m + 1, firstc = 0, lastc = 0;
 #pragma unroll 4
                 for (int c = 0; c < ncol; c++) {
-                    myers_step<unsigned, true>(peq[cw[c] * NBs], Pvv, Mv, score, top);
+                    myers_step<unsigned, true>(peq[(int)cw[c] << lNBs], Pvv, Mv, score, top);
                     bool lt = score < best;
                     best = lt ? score : best;
                     firstc = lt ? c : firstc;
@@ -1084,6 +1085,12 @@ extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
                          : hipFuncSetAttribute((const void *)smx::demux_kernel<unsigned>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return (int)e;
+}
+
+extern "C" int smx_query_occupancy(int use64, size_t lds_bytes, int *blocks_per_cu) {
+    hipError_t e = use64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, smx::demux_kernel<unsigned long long>, 256, lds_bytes)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, smx::demux_kernel<unsigned>, 256, lds_bytes);
     return (int)e;
 }
 

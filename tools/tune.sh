@@ -9,8 +9,10 @@ for cfg in "$@"; do
       B=*) env_args="$env_args SMX_BLOCKS_PER_CU=${kv#B=}";;
       L=*) env_args="$env_args SMX_LDS_BUDGET=${kv#L=}";;
       T=*) env_args="$env_args SMX_PHASE_TIMING=1";;
+      P=*) env_args="$env_args SMX_LDS_PAD=${kv#P=}";;
+      D=*) env_args="$env_args SMX_DEBUG=1";;
     esac
   done
   out=$(env $env_args python bench.py --no-cpu-baseline --steps 10 --warmup 2 2>gpurun_out/tune.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.1f Mreads/s kernel %.3f ms' % (d['value']/1e6, d['roofline']['kernel_ms_avg']))")
-  echo "[$cfg] $out $(grep 'phase timing' gpurun_out/tune.err | tail -1)"
+  echo "[$cfg] $out $(grep -E 'phase timing|occupancy API' gpurun_out/tune.err | tail -2 | tr '\n' ' ')"
 done

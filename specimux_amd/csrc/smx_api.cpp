@@ -99,8 +99,10 @@ struct smx_panel {
     size_t o_ppeq, o_prpeq, o_bpeq, o_lut, o_pm, o_pk, o_pdir, o_pfidx, o_pbc_off, o_pbc, o_bm, o_pair_f, o_pair_r,
         o_pair_pool, o_pairhead, o_spec_next, o_p1m, o_p2m, o_spec_pool;
     int use64 = 0;
-    int R = 0;
+    int R = 0;          // lean mode tile (no per-barcode slots)
     size_t lds = 0;
+    int R_slots = 0;    // slots mode tile (--trim tails, parity dumps)
+    size_t lds_slots = 0;
     // device state (lazy, one device per process)
     void *d_blob = nullptr;
     int device = -1;
@@ -235,19 +237,23 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     P->o_p1m = blob_add(B, p1m); P->o_p2m = blob_add(B, p2m); P->o_spec_pool = blob_add(B, spec_pool);
 
     P->use64 = maxm > 32 ? 1 : 0;
-    // tile size: largest R in {64, 32, ...} whose LDS image lets 3 workgroups share a CU's 160 KiB
+    // tile size: largest R in {64, 32, ...} whose LDS image lets 4 workgroups share a CU's 160 KiB
     // (SMX_TILE_R / SMX_LDS_BUDGET override for tuning experiments)
-    size_t budget = (160 * 1024) / 3;
+    size_t budget = 40 * 1024;   // 4 workgroups per CU (VGPR-limited to 4 waves/SIMD anyway)
     if (const char *e = getenv("SMX_LDS_BUDGET")) budget = (size_t)atol(e);
     int rmax = 64;
     if (const char *e = getenv("SMX_TILE_R")) rmax = std::max(1, std::min(64, atoi(e)));
-    for (int R = rmax; R >= 1; R >>= 1) {
-        size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts,
-                                          5 * NP + 1 + h.n_pbc + NB + 3 * NPAIR);
-        if (need <= budget || R == 1) { P->R = R; P->lds = need; break; }
-    }
+    const int npmeta = 5 * NP + 1 + h.n_pbc + NB + 3 * NPAIR;
+    for (int slots = 0; slots < 2; slots++)
+        for (int R = rmax; R >= 1; R >>= 1) {
+            size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, slots);
+            if (need <= budget || R == 1) {
+                if (slots) { P->R_slots = R; P->lds_slots = need; } else { P->R = R; P->lds = need; }
+                break;
+            }
+        }
     if (const char *e = getenv("SMX_LDS_PAD")) P->lds += (size_t)atol(e);   // tuning experiment: residency vs LDS size
-    if (P->lds > 160 * 1024) { delete P; return fail(SMX_ERR_UNSUPPORTED, "panel needs %zu bytes of LDS per read tile", P->lds); }
+    if (P->lds > 160 * 1024 || P->lds_slots > 160 * 1024) { delete P; return fail(SMX_ERR_UNSUPPORTED, "panel needs %zu bytes of LDS per read tile", std::max(P->lds, P->lds_slots)); }
     *out = P;
     return SMX_OK;
 }
@@ -324,18 +330,17 @@ static int ensure_device(smx_panel *P) {
     h.pairhead = (const int *)(b + P->o_pairhead); h.spec_next = (const int *)(b + P->o_spec_next);
     h.spec_p1m = (const unsigned long long *)(b + P->o_p1m); h.spec_p2m = (const unsigned long long *)(b + P->o_p2m);
     h.spec_pool = (const int *)(b + P->o_spec_pool);
-    if (P->lds > 64 * 1024) {
-        int rc = smx_set_demux_lds_limit(P->use64, P->lds);
-        if (rc != 0) return fail(SMX_ERR_DEVICE, "cannot raise the dynamic LDS limit to %zu bytes", P->lds);
+    if (std::max(P->lds, P->lds_slots) > 64 * 1024) {
+        int rc = smx_set_demux_lds_limit(P->use64, std::max(P->lds, P->lds_slots));
+        if (rc != 0) return fail(SMX_ERR_DEVICE, "cannot raise the dynamic LDS limit to %zu bytes", std::max(P->lds, P->lds_slots));
     }
-    size_t per_cu = (160 * 1024) / std::max<size_t>(P->lds, 1);
-    P->blocks_per_cu = (int)std::min<size_t>(std::max<size_t>(per_cu, 1), 8);
+    P->blocks_per_cu = 8;   // persistent grid; tiles are pulled from a queue, so over-subscription is harmless
     if (const char *e = getenv("SMX_BLOCKS_PER_CU")) P->blocks_per_cu = std::max(1, atoi(e));
     if (getenv("SMX_DEBUG")) {
         int occ = -1;
         (void)smx_query_occupancy(P->use64, P->lds, &occ);
-        fprintf(stderr, "[smx] R=%d lds=%zu occupancy API: %d blocks/CU, grid multiplier %d, CUs %d\n", P->R, P->lds, occ,
-                P->blocks_per_cu, P->n_cu);
+        fprintf(stderr, "[smx] lean R=%d lds=%zu | slots R=%d lds=%zu | occupancy API (lean): %d blocks/CU, grid multiplier %d, CUs %d\n",
+                P->R, P->lds, P->R_slots, P->lds_slots, occ, P->blocks_per_cu, P->n_cu);
     }
     if (getenv("SMX_PHASE_TIMING")) {
         P->phase_grid = P->n_cu * P->blocks_per_cu;
@@ -356,10 +361,14 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     int rc = ensure_device(P);
     if (rc) return rc;
     if (n_reads == 0) return SMX_OK;
-    uint32_t tiles = (n_reads + P->R - 1) / P->R;
+    // slots mode keeps one result slot per (hit, barcode): needed for the tails extent and for the parity dumps
+    const int use_slots = (P->hp.trim == SMX_TRIM_TAILS || d_hits || d_bdist || getenv("SMX_FORCE_SLOTS")) ? 1 : 0;
+    const int R = use_slots ? P->R_slots : P->R;
+    const size_t lds = use_slots ? P->lds_slots : P->lds;
+    uint32_t tiles = (n_reads + R - 1) / R;
     int grid = (int)std::min<uint32_t>(tiles, (uint32_t)(P->n_cu * P->blocks_per_cu));
-    int e = smx_launch_demux(&P->hp, P->use64, P->R, grid, P->lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
-                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, P->d_tile_counter);
+    int e = smx_launch_demux(&P->hp, P->use64, R, grid, lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
+                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, P->d_tile_counter, use_slots);
     if (e != 0) return fail(SMX_ERR_DEVICE, "demux kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return SMX_OK;
 }

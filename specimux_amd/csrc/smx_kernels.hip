@@ -80,8 +80,7 @@ __device__ __forceinline__ BcGeom bc_geom(int L, int base, int bstart) {
 // ------------------------------------------------------------------------------------------------
 // LDS-resident per (read, primer, end) record.
 struct HitL {
-    int tail_end;       // reference coord: max optimal end over all within-k barcodes, valid if bbest >= 0
-    int bfirst_end;     // reference coord: first optimal end of the first tied barcode
+    int tail_end;       // reference coord: max optimal end over all within-k barcodes (slots mode), valid if bbest >= 0
     short pdist;        // -1 no primer match
     short nloc;
     short bbest;        // -1 none, -2 not searched
@@ -90,14 +89,14 @@ struct HitL {
     unsigned char jstar;   // window position of the first optimal primer end
     unsigned char fs_j;    // window position of its start (need_starts only)
     unsigned char flags;   // bit0: orientation vote, bit1: barcode search needed
-    unsigned char pad;
+    unsigned char pad[3];
 };
-static_assert(sizeof(HitL) == 24, "HitL layout");
+static_assert(sizeof(HitL) == 20, "HitL layout");
 
 #define SMX_MAX_EMIT 16
 
 struct TileLayout {   // byte offsets into dynamic LDS
-    int ppeq, prpeq, bpeq, lut, pmeta, codes, lens, ocnt, hits, masks, tiem, bres, ents, offsA, offsB, queue, emit, opsL, aggr,
+    int ppeq, prpeq, bpeq, lut, pmeta, codes, namask, lens, ocnt, hits, masks, tiem, bres, dmask, ents, offsA, offsB, queue, emit, opsL, aggr,
         total;
     int CS;      // bytes per code row (odd number of dwords: conflict-free column reads across rows)
     int lNPs, lNBs;  // their log2
@@ -119,7 +118,7 @@ static_assert(sizeof(EntL) == 8, "EntL layout");
 
 template <typename PW>
 __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, int maxB, int need_starts,
-                                                    int npmeta) {
+                                                    int npmeta, int kidx, int slots) {
     TileLayout t;
     int H = 2 * NP, MW = (S + 31) / 32;
     t.CS = 4 * (((S + 3) / 4) | 1);
@@ -128,11 +127,13 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.G = 1; t.logG = 0;
     while (t.G < maxB) { t.G <<= 1; t.logG++; }
     t.MBW = (maxB + 31) / 32;
-    // barcode rounds: all hits of the tile at once when that costs <= 16 KiB of slots, else 16 KiB worth
+    // barcode rounds.  slots mode (--trim tails, parity dumps): one 4-byte atomicMin slot per (hit, barcode),
+    // at most 16 KiB worth of hits per round.  lean mode: per hit only (k+1) x MBW words of "barcodes seen at
+    // distance d" bitmasks, at most 4 KiB per round.
     int dense = R * H;
-    int fit = (16 * 1024) / (t.G * 4);
+    int fit = slots ? (16 * 1024) / (t.G * 4) : (4 * 1024) / ((kidx + 1) * t.MBW * 4);
     t.CAPH = dense < fit ? dense : (fit < 1 ? 1 : fit);
-    t.CAPE = 2 * t.CAPH < 320 ? 320 : 2 * t.CAPH;   // >= 256 = max locations of one hit (progress guarantee)
+    t.CAPE = t.CAPH + t.CAPH / 4 < 320 ? 320 : t.CAPH + t.CAPH / 4;   // >= 256 = max locations of one hit (progress)
     int o = 0;
     t.ppeq = o;  o += t.NPs * 16 * (int)sizeof(PW);
     t.prpeq = o; o += (need_starts ? t.NPs * 16 * (int)sizeof(PW) : 0);
@@ -141,19 +142,24 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.pmeta = o; o += npmeta * 4;
     o = (o + 15) & ~15;
     t.codes = o; o += R * 2 * t.CS;
+    t.namask = o; o += R * 2 * (MW + 1) * 4;   // per code row: bit j set = code[j] is not A/C/G/T (+1 guard word)
     t.lens = o;  o += R * 4;
     t.ocnt = o;  o += R * 2 * 4;
     t.hits = o;  o += R * H * (int)sizeof(HitL);
     t.masks = o; o += R * H * MW * 4;
     t.tiem = o;  o += R * H * t.MBW * 4;
-    t.bres = o;  o += t.CAPH * t.G * 4;
-    t.ents = o;  o += t.CAPE * (int)sizeof(EntL);
+    // two time-shared regions: {slots | distance bitmasks} are dead once the scorer starts -> emission log;
+    // {location entries} are dead after the barcode scan -> staged result records
+    {
+        int a = slots ? t.CAPH * t.G * 4 : t.CAPH * (kidx + 1) * t.MBW * 4, b = R * SMX_MAX_EMIT * 4;
+        t.bres = t.dmask = t.emit = o; o += a > b ? a : b;
+        int c = t.CAPE * (int)sizeof(EntL), d = R * 32;
+        o = (o + 15) & ~15;
+        t.ents = t.opsL = o; o += c > d ? c : d;
+    }
     t.offsA = o; o += (R * H + 1) * 4;
     t.offsB = o; o += (R * H + 1) * 4;
     t.queue = o; o += ((R * H + 1) & ~1) * 2;
-    t.emit = o;  o += R * SMX_MAX_EMIT * 4;
-    o = (o + 15) & ~15;
-    t.opsL = o;  o += R * 32;
     t.aggr = o;  o += 12 * 4;
     t.total = (o + 15) & ~15;
     return t;
@@ -591,24 +597,26 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
                                                     unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist,
-                                                    unsigned *tile_counter) {
+                                                    unsigned *tile_counter, int use_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
     const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
     const int n_pbc = P->n_pbc, NPAIR = P->NPAIR;
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
-    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta);
+    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta, P->kidx, use_slots);
     PW *ppeq = (PW *)(lds + T.ppeq);        // [code][primer], stride NPs
     PW *prpeq = (PW *)(lds + T.prpeq);
     unsigned *bpeq = (unsigned *)(lds + T.bpeq);   // [code][barcode], stride NBs
     unsigned char *lut = lds + T.lut;
     unsigned char *codes = lds + T.codes;
+    unsigned *namask = (unsigned *)(lds + T.namask);
     int *lensL = (int *)(lds + T.lens);
     int *ocnt = (int *)(lds + T.ocnt);
     HitL *hits = (HitL *)(lds + T.hits);
     unsigned *masks = (unsigned *)(lds + T.masks);
     unsigned *tiem = (unsigned *)(lds + T.tiem);
     unsigned *bres = (unsigned *)(lds + T.bres);
+    unsigned *dmask = (unsigned *)(lds + T.dmask);   // lean mode: [hit in round][distance][MBW] barcode bitmasks
     EntL *ents = (EntL *)(lds + T.ents);
     int *offsA = (int *)(lds + T.offsA);    // exclusive scan of searched locations per hit
     int *offsB = (int *)(lds + T.offsB);    // exclusive scan of searched hits (rank)
@@ -669,6 +677,7 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
 
         // ---- phase 1: windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
         if (tid < nr) { lensL[tid] = lens[r0 + tid]; ocnt[2 * tid] = 0; ocnt[2 * tid + 1] = 0; }
+        for (int i = tid; i < nr * 2 * (MW + 1); i += 256) namask[i] = 0;
         __syncthreads();
         {
             const int chunks = stride / 16;
@@ -680,15 +689,32 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                 int Sp = L < S ? L : S;
                 unsigned w[4] = {v.x, v.y, v.z, v.w};
                 unsigned char *rowA = codes + (r * 2 + 0) * CS, *rowB = codes + (r * 2 + 1) * CS;
+                unsigned nam = 0;   // bit b: byte b of this chunk is a live non-ACGT base
 #pragma unroll
                 for (int b = 0; b < 16; b++) {
                     int pos = cpos + b;
                     unsigned ch = (w[b >> 2] >> ((b & 3) * 8)) & 0xFF;
                     if (pos < S) {            // head byte i -> A[Sp-1-i] = code(complement)
-                        if (pos < Sp) rowA[Sp - 1 - pos] = lut[256 + ch];
+                        if (pos < Sp) {
+                            unsigned cd = lut[256 + ch];
+                            rowA[Sp - 1 - pos] = (unsigned char)cd;
+                            nam |= (cd > 3 ? 1u : 0u) << b;
+                        }
                     } else if (pos < 2 * S) { // tail byte j -> B[j]
                         int j = pos - S;
-                        if (j < Sp) rowB[j] = lut[ch];
+                        if (j < Sp) {
+                            unsigned cd = lut[ch];
+                            rowB[j] = (unsigned char)cd;
+                            nam |= (cd > 3 ? 1u : 0u) << b;
+                        }
+                    }
+                }
+                if (nam) {   // rare: scatter the flags into the per-row bitmasks used by the prefilter rule
+                    for (int b = 0; b < 16; b++) {
+                        if (!((nam >> b) & 1)) continue;
+                        int pos = cpos + b;
+                        int row = pos < S ? 0 : 1, j = pos < S ? Sp - 1 - pos : pos - S;
+                        atomicOr(&namask[(r * 2 + row) * (MW + 1) + (j >> 5)], 1u << (j & 31));
                     }
                 }
             }
@@ -768,12 +794,12 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                 fs_j = jstar - (lastc - 1);
             }
             HitL hl;
-            hl.tail_end = -1; hl.bfirst_end = -1;
+            hl.tail_end = -1;
             hl.pdist = (short)(matched ? best : -1);
             hl.nloc = (short)(matched ? cnt : 0);
             hl.bbest = -2; hl.ntied = 0; hl.first_tied = -1;
             hl.jstar = (unsigned char)jstar; hl.fs_j = (unsigned char)fs_j;
-            hl.flags = (unsigned char)(omatch ? 1 : 0); hl.pad = 0;
+            hl.flags = (unsigned char)(omatch ? 1 : 0); hl.pad[0] = hl.pad[1] = hl.pad[2] = 0;
             hits[item] = hl;
             if (omatch) {
                 // determine_orientation via A.6: fwd primer in A / rev primer in B vote "forward"
@@ -850,7 +876,7 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                 int L = lensL[r];
                 EndGeom g = end_geom(L, S);
                 const unsigned *mrow = masks + (size_t)item * MW;
-                const unsigned char *cw = codes + (r * 2 + X) * CS;
+                const unsigned *na = namask + (r * 2 + X) * (MW + 1);
                 int e = offsA[item] - e_base, ord = 0;
                 for (int w = hl.jstar >> 5; w < MW; w++) {
                     unsigned word = mrow[w];
@@ -864,7 +890,11 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                         bool ok = ncol > 0;
                         if (ok && pfmin > 0) {   // exact-set restatement of BloomPrefilter.match (Q7)
                             if (!bg.pf_same || ncol < pfmin) ok = false;
-                            else for (int c = 0; c < pfmin; c++) if (cw[bg.tj0 + c] > 3) { ok = false; break; }
+                            else {   // any non-ACGT code among target[0 : pfmin) ?
+                                int wi = bg.tj0 >> 5, sh = bg.tj0 & 31;
+                                unsigned long long two = ((unsigned long long)na[wi + 1] << 32) | na[wi];
+                                if ((two >> sh) & ((1ull << pfmin) - 1ull)) ok = false;
+                            }
                         }
                         EntL en;
                         en.hit = (unsigned short)item;
@@ -878,7 +908,8 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                     }
                 }
             }
-            for (int i = tid; i < ((q1 - q0) << logG); i += 256) bres[i] = 0xFFFFFFFFu;
+            if (use_slots) { for (int i = tid; i < ((q1 - q0) << logG); i += 256) bres[i] = 0xFFFFFFFFu; }
+            else { for (int i = tid; i < (q1 - q0) * (kidx + 1) * MBW; i += 256) dmask[i] = 0; }
             __syncthreads();
             STAMP(3);
 
@@ -904,14 +935,85 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                     firstc = lt ? c : firstc;
                     lastc = (score == best) ? c : lastc;
                 }
-                if (best <= kidx)
-                    atomicMin(&bres[en.slot + bi], ((unsigned)best << 24) | ((unsigned)en.loc_ord << 16) |
-                                                       ((unsigned)(en.tj0 + firstc) << 8) | (unsigned)(en.tj0 + lastc));
+                if (best <= kidx) {
+                    if (use_slots)
+                        atomicMin(&bres[en.slot + bi], ((unsigned)best << 24) | ((unsigned)en.loc_ord << 16) |
+                                                           ((unsigned)(en.tj0 + firstc) << 8) | (unsigned)(en.tj0 + lastc));
+                    else   // barcode bi seen at distance `best` (any location): the lowest non-empty level wins
+                        atomicOr(&dmask[(((en.slot >> logG) * (kidx + 1)) + best) * MBW + (bi >> 5)], 1u << (bi & 31));
+                }
             }
             __syncthreads();
             STAMP(4);
 
-            // 3c: per searched hit: best distance, tie set, tails extent
+            // 3c: per searched hit: best distance, tie set (ballot), tails extent.  Lanes = (hit, barcode slot):
+            // group-of-G reductions by xor-shuffles, the tie bitmask straight from the ballot.
+            if (!use_slots) {
+                // lean mode: best = lowest distance level with any barcode, tie set = that level's bitmask
+                for (int q = q0 + tid; q < q1; q += 256) {
+                    int item = queue[q];
+                    const unsigned *dm = dmask + (q - q0) * (kidx + 1) * MBW;
+                    for (int d = 0; d <= kidx; d++) {
+                        int nt = 0, first = -1;
+                        for (int w = 0; w < MBW; w++) {
+                            unsigned m = dm[d * MBW + w];
+                            if (m && first < 0) first = w * 32 + __ffs(m) - 1;
+                            nt += __popc(m);
+                        }
+                        if (nt) {
+                            HitL &hl = hits[item];
+                            hl.bbest = (short)d; hl.ntied = (short)nt; hl.first_tied = (short)first;
+                            for (int w = 0; w < MBW; w++) tiem[item * MBW + w] = dm[d * MBW + w];
+                            break;
+                        }
+                    }
+                }
+            } else if (G <= 64) {
+                const int nslots = (q1 - q0) << logG;
+                for (int base_i = wave * 64; base_i < nslots; base_i += 256) {
+                    const int i = base_i + (tid & 63);
+                    const bool in = i < nslots;
+                    const int q = q0 + ((in ? i : 0) >> logG), sl = i & (G - 1);
+                    const int item = queue[q];
+                    const int r = item / H, h = item - r * H, p = h >> 1;
+                    const int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
+                    const bool live = in && sl < nb;
+                    unsigned v = live ? bres[i] : 0xFFFFFFFFu;
+                    if (live && dbg_bdist)
+                        dbg_bdist[(size_t)r0 * H * maxB + (size_t)item * maxB + sl] = (v == 0xFFFFFFFFu) ? (int8_t)-1 : (int8_t)(v >> 24);
+                    const int L = lensL[r];
+                    const EndGeom g = end_geom(L, S);
+                    int last_abs = -0x7FFFFFFF;
+                    if (v != 0xFFFFFFFFu) {
+                        int delta = 0;
+                        if (L < S) {   // short read: the location's slice start may have wrapped (Q1)
+                            int je = nth_location(masks + (size_t)item * MW, MW, hits[item].jstar, (v >> 16) & 0xFF);
+                            delta = bc_geom(L, g.base, (je - g.j_lo) + g.shift + 1).delta;
+                        }
+                        last_abs = (int)(v & 0xFF) + g.base - delta;
+                    }
+                    unsigned dmin = v >> 24;
+                    int tail = last_abs;
+                    for (int d = 1; d < G; d <<= 1) {
+                        unsigned o = (unsigned)__shfl_xor((int)dmin, d, 64);
+                        int t = __shfl_xor(tail, d, 64);
+                        dmin = o < dmin ? o : dmin;
+                        tail = t > tail ? t : tail;
+                    }
+                    const bool tied = (v >> 24) == dmin && dmin != 255;
+                    unsigned long long bal = __ballot(tied);
+                    const int gshift = (tid & 63) & ~(G - 1);
+                    unsigned long long gm = (G == 64) ? bal : ((bal >> gshift) & ((1ull << G) - 1ull));
+                    int first = gm ? __ffsll((long long)gm) - 1 : 0;
+                    if (in && sl == 0 && dmin != 255) {
+                        HitL &hl = hits[item];
+                        hl.bbest = (short)dmin; hl.ntied = (short)__popcll(gm); hl.first_tied = (short)first;
+                        hl.tail_end = tail;
+                        tiem[item * MBW] = (unsigned)gm;
+                        if (MBW > 1) tiem[item * MBW + 1] = (unsigned)(gm >> 32);
+                    }
+                }
+            } else
             for (int q = q0 + tid; q < q1; q += 256) {
                 int item = queue[q];
                 HitL &hl = hits[item];
@@ -927,7 +1029,7 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                 if (best == 255) continue;
                 int L = lensL[r];
                 EndGeom g = end_geom(L, S);
-                int ntied = 0, first = -1, tail = -0x7FFFFFFF, bfirst = -1;
+                int ntied = 0, first = -1, tail = -0x7FFFFFFF;
                 for (int i = 0; i < nb; i++) {
                     unsigned v = br[i];
                     if (v == 0xFFFFFFFFu) continue;
@@ -937,16 +1039,15 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                         delta = bc_geom(L, g.base, (je - g.j_lo) + g.shift + 1).delta;
                     }
                     int last_abs = (int)(v & 0xFF) + g.base - delta;
-                    int first_abs = (int)((v >> 8) & 0xFF) + g.base - delta;
                     tail = last_abs > tail ? last_abs : tail;
                     if ((v >> 24) == best) {
-                        if (ntied == 0) { first = i; bfirst = first_abs; }
+                        if (ntied == 0) first = i;
                         ntied++;
                         tiem[item * MBW + (i >> 5)] |= 1u << (i & 31);
                     }
                 }
                 hl.bbest = (short)best; hl.ntied = (short)ntied; hl.first_tied = (short)first;
-                hl.tail_end = tail; hl.bfirst_end = bfirst;
+                hl.tail_end = tail;
             }
             __syncthreads();
             STAMP(5);
@@ -1060,24 +1161,25 @@ __global__ void align_kernel(const unsigned long long *peq, const unsigned long 
 extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t lds_bytes, void *stream,
                                 const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops,
                                 smx_op *d_extra, uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts,
-                                smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter) {
+                                smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter, int use_slots) {
     hipStream_t s = (hipStream_t)stream;
     hipError_t me = hipMemsetAsync(d_tile_counter, 0, sizeof(unsigned), s);
     if (me != hipSuccess) return (int)me;
     if (use64)
         hipLaunchKernelGGL(smx::demux_kernel<unsigned long long>, dim3(grid), dim3(256), lds_bytes, s, *P, d_windows,
                            d_lens, n_reads, R, d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts,
-                           d_hits, d_bdist, d_tile_counter);
+                           d_hits, d_bdist, d_tile_counter, use_slots);
     else
         hipLaunchKernelGGL(smx::demux_kernel<unsigned>, dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens,
                            n_reads, R, d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits,
-                           d_bdist, d_tile_counter);
+                           d_bdist, d_tile_counter, use_slots);
     return (int)hipGetLastError();
 }
 
-extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta) {
-    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta).total
-                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta).total;
+extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta,
+                                      int kidx, int slots) {
+    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots).total
+                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots).total;
 }
 
 extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {

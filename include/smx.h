@@ -206,6 +206,55 @@ int smx_comm_init(const uint8_t id[128], int n_ranks, int rank, void **comm_out)
 int smx_counts_allreduce(uint64_t *d_counts, size_t n, void *comm, void *stream);
 void smx_comm_destroy(void *comm);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Host streaming helpers: the steps on either side of the hot path.
+ *
+ *   smx_reader_*            <- open_sequence_file / SeqIO.parse + iter_batches
+ *                              (src/specimux/io_utils.py:380-450, orchestration.py:447-456): FASTQ / FASTA,
+ *                              plain or gzip; id = first whitespace-delimited word of the title; wrapped
+ *                              sequence / quality lines accepted (Biopython FastqGeneralIterator rules)
+ *   smx_pack_windows_batch  <- the end slices of match_one_end, straight from a parsed batch
+ *   smx_writer_*            <- create_write_operation's slicing + OutputManager.write_sequence
+ *                              (demultiplex.py:74-78, io_utils.py:197-268): orientation, trim, header
+ *                              "{id} {p1d,b1d,b2d,p2d} pool={pool} primers={p1}+{p2} {sample}", path
+ *                              {full|partial|unknown}/{pool}/{p1}-{p2}/{prefix}{sample}.{fastq|fasta} and the
+ *                              pool-level copy of full matches.  Append-only, buffered per file.
+ * Pure host code (no device work); a batch owns its memory, so reading batch i+1 may overlap the GPU run
+ * of batch i and the writing of batch i-1 from different threads.
+ */
+typedef struct smx_reader smx_reader;
+typedef struct smx_batch smx_batch;
+typedef struct smx_writer smx_writer;
+
+int smx_reader_open(const char *path, smx_reader **out, int *is_fastq);
+void smx_reader_close(smx_reader *reader);
+smx_batch *smx_batch_new(void);
+void smx_batch_free(smx_batch *batch);
+/* parse up to max_reads records (and at most ~max_bytes of sequence data, 0 = no limit) into `batch`;
+ * *n_read = 0 at end of file */
+int smx_reader_next(smx_reader *reader, uint32_t max_reads, uint64_t max_bytes, smx_batch *batch, uint32_t *n_read);
+uint32_t smx_batch_size(const smx_batch *batch);
+/* record i: pointers into the batch (valid until the batch is refilled or freed); qual == NULL for FASTA */
+int smx_batch_record(const smx_batch *batch, uint32_t i, const char **id, uint32_t *id_len, const char **seq,
+                     const char **qual, uint32_t *seq_len);
+int smx_pack_windows_batch(const smx_batch *batch, int32_t search_len, uint8_t *windows, int32_t *lens);
+
+/* index -> name tables for the record headers and paths: concatenated strings with n+1 offsets each */
+typedef struct smx_names {
+    const char *specimens; const uint32_t *specimen_off; uint32_t n_specimens;
+    const char *pools;     const uint32_t *pool_off;     uint32_t n_pools;
+    const char *primers;   const uint32_t *primer_off;   uint32_t n_primers;
+    const char *barcodes;  const uint32_t *barcode_off;  uint32_t n_barcodes;
+} smx_names;
+
+int smx_writer_open(const char *output_dir, const char *prefix, int is_fastq, const smx_names *names,
+                    smx_writer **out);
+/* format and append every write operation of the batch: ops[n_reads] primary records + extra[n_extra] */
+int smx_writer_write(smx_writer *writer, const smx_batch *batch, const smx_op *ops, uint32_t n_reads,
+                     const smx_op *extra, uint32_t n_extra);
+int smx_writer_close(smx_writer *writer);   /* flushes; returns the first I/O error seen, if any */
+
 #ifdef __cplusplus
 }
 #endif

@@ -581,7 +581,7 @@ def resolve_specimen(m, panel):  # demultiplex.py:541-598
 class Op:
     """WriteOperation (models.py:341-357), only the fields that reach a file/stdout."""
     __slots__ = ("sample_id", "seq_id", "code", "sequence", "quality", "pool", "p1", "p2", "rtype",
-                 "p1_loc", "p2_loc", "b1_loc", "b2_loc")
+                 "p1_loc", "p2_loc", "b1_loc", "b2_loc", "trim", "reverse")
 
     def key(self):
         return (self.seq_id, self.sample_id, self.code, self.pool, self.p1, self.p2, self.rtype,
@@ -592,6 +592,7 @@ def make_op(sample_id, par, m, rtype):  # demultiplex.py:30-103
     sid, bases, quals = m.seq
     op = Op()
     op.seq_id, op.code = sid, m.code()
+    op.trim, op.reverse = (0, len(bases)), m.rev     # extent actually cut from the oriented read (tests only)
     fallback = False
     if par.trim != "none":
         s, e = m.extent(par.trim)
@@ -599,6 +600,7 @@ def make_op(sample_id, par, m, rtype):  # demultiplex.py:30-103
             fallback = True
         else:
             bases, quals = bases[s:e], quals[s:e]
+            op.trim = (s, e)
             m.trim_locations(s)  # Q8: mutates the candidate for any later emission
     op.p1_loc = m.p1m.locs[0] if m.p1m else None
     op.p2_loc = m.p2m.locs[0] if m.p2m else None

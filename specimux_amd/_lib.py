@@ -62,7 +62,27 @@ SYMBOLS = [
     ("smx_comm_init", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     ("smx_counts_allreduce", C.c_int, [_P, C.c_size_t, _P, _P]),
     ("smx_comm_destroy", None, [_P]),
+    # host streaming helpers
+    ("smx_reader_open", C.c_int, [C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int)]),
+    ("smx_reader_close", None, [_P]),
+    ("smx_batch_new", _P, []),
+    ("smx_batch_free", None, [_P]),
+    ("smx_reader_next", C.c_int, [_P, C.c_uint32, C.c_uint64, _P, C.POINTER(C.c_uint32)]),
+    ("smx_batch_size", C.c_uint32, [_P]),
+    ("smx_batch_record", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
+                                   C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_uint32)]),
+    ("smx_pack_windows_batch", C.c_int, [_P, C.c_int32, _P, _P]),
+    ("smx_writer_open", C.c_int, [C.c_char_p, C.c_char_p, C.c_int, _P, C.POINTER(_P)]),
+    ("smx_writer_write", C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32]),
+    ("smx_writer_close", C.c_int, [_P]),
 ]
+
+
+class Names(C.Structure):
+    _fields_ = [("specimens", C.c_char_p), ("specimen_off", C.c_void_p), ("n_specimens", C.c_uint32),
+                ("pools", C.c_char_p), ("pool_off", C.c_void_p), ("n_pools", C.c_uint32),
+                ("primers", C.c_char_p), ("primer_off", C.c_void_p), ("n_primers", C.c_uint32),
+                ("barcodes", C.c_char_p), ("barcode_off", C.c_void_p), ("n_barcodes", C.c_uint32)]
 
 
 class SmxError(RuntimeError):

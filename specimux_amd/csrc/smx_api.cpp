@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -93,6 +94,21 @@ size_t blob_add(std::vector<unsigned char> &blob, const std::vector<T> &v) {
 
 }  // namespace
 
+struct DevBuf {   // grow-only device buffer of the host-buffer convenience path
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
 struct smx_panel {
     smx::DevPanel hp;                 // scalar fields valid; pointers filled at upload
     std::vector<unsigned char> blob;  // host image of the device allocation
@@ -108,12 +124,25 @@ struct smx_panel {
     int device = -1;
     int n_cu = 0;
     int blocks_per_cu = 1;
+    std::mutex ws_mutex;                     // smx_batch_run is serialised per panel (one workspace)
+    DevBuf ws[8];                            // windows, lens, ops, extra, n_extra, counts, hits, bdist
     unsigned *d_tile_counter = nullptr;      // dynamic tile queue head (zeroed on the stream before each launch)
     unsigned long long *d_phase = nullptr;   // SMX_PHASE_TIMING diagnostic
     int phase_grid = 0;
 };
 
 extern "C" {
+
+// shared with smx_io.cpp: set the thread-local message and return `code`
+int smx_set_error(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
 
 int smx_abi_version(void) { return SMX_ABI_VERSION; }
 const char *smx_last_error(void) { return g_err.c_str(); }
@@ -276,6 +305,7 @@ void smx_panel_destroy(smx_panel *P) {
     }
     if (P->d_blob) (void)hipFree(P->d_blob);
     if (P->d_tile_counter) (void)hipFree(P->d_tile_counter);
+    for (auto &b : P->ws) b.release();
     delete P;
 }
 
@@ -384,28 +414,26 @@ int smx_batch_run(const smx_panel *Pc, const uint8_t *windows, const int32_t *le
     const size_t wbytes = (size_t)n_reads * P->hp.wstride, ncnt = smx_counts_len(P);
     const size_t hbytes = hits ? (size_t)n_reads * smx_hits_per_read(P) * sizeof(smx_hit) : 0;
     const size_t bbytes = bdist ? (size_t)n_reads * smx_bdist_per_read(P) : 0;
-    unsigned char *dw = nullptr, *dl = nullptr, *dop = nullptr, *dex = nullptr, *dn = nullptr, *dc = nullptr, *dh = nullptr,
-                  *db = nullptr;
-    auto cleanup = [&]() {
-        for (void *p : {(void *)dw, (void *)dl, (void *)dop, (void *)dex, (void *)dn, (void *)dc, (void *)dh, (void *)db})
-            if (p) (void)hipFree(p);
-    };
-#define TRY_C(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(SMX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); } } while (0)
-    TRY_C(hipMalloc((void **)&dw, wbytes));
-    TRY_C(hipMalloc((void **)&dl, (size_t)n_reads * 4));
-    TRY_C(hipMalloc((void **)&dop, (size_t)n_reads * sizeof(smx_op)));
-    TRY_C(hipMalloc((void **)&dex, std::max<size_t>((size_t)extra_cap * sizeof(smx_op), 32)));
-    TRY_C(hipMalloc((void **)&dn, 16));
-    TRY_C(hipMalloc((void **)&dc, ncnt * 8));
-    if (hits) TRY_C(hipMalloc((void **)&dh, hbytes));
-    if (bdist) TRY_C(hipMalloc((void **)&db, bbytes));
+    std::lock_guard<std::mutex> guard(P->ws_mutex);
+#define TRY_C(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(SMX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); } while (0)
+    TRY_C(P->ws[0].ensure(wbytes));
+    TRY_C(P->ws[1].ensure((size_t)n_reads * 4));
+    TRY_C(P->ws[2].ensure((size_t)n_reads * sizeof(smx_op)));
+    TRY_C(P->ws[3].ensure(std::max<size_t>((size_t)extra_cap * sizeof(smx_op), 32)));
+    TRY_C(P->ws[4].ensure(16));
+    TRY_C(P->ws[5].ensure(ncnt * 8));
+    if (hits) TRY_C(P->ws[6].ensure(hbytes));
+    if (bdist) TRY_C(P->ws[7].ensure(bbytes));
+    unsigned char *dw = (unsigned char *)P->ws[0].p, *dl = (unsigned char *)P->ws[1].p, *dop = (unsigned char *)P->ws[2].p,
+                  *dex = (unsigned char *)P->ws[3].p, *dn = (unsigned char *)P->ws[4].p, *dc = (unsigned char *)P->ws[5].p,
+                  *dh = hits ? (unsigned char *)P->ws[6].p : nullptr, *db = bdist ? (unsigned char *)P->ws[7].p : nullptr;
     TRY_C(hipMemcpy(dw, windows, wbytes, hipMemcpyHostToDevice));
     TRY_C(hipMemcpy(dl, lens, (size_t)n_reads * 4, hipMemcpyHostToDevice));
     TRY_C(hipMemset(dn, 0, 16));
     TRY_C(hipMemset(dc, 0, ncnt * 8));
     rc = smx_batch_run_device(P, nullptr, dw, (const int32_t *)dl, n_reads, (smx_op *)dop, (smx_op *)dex, extra_cap,
                               (uint32_t *)dn, (uint64_t *)dc, (smx_hit *)dh, (int8_t *)db);
-    if (rc) { cleanup(); return rc; }
+    if (rc) return rc;
     TRY_C(hipDeviceSynchronize());
     std::vector<uint64_t> c(ncnt);
     TRY_C(hipMemcpy(ops, dop, (size_t)n_reads * sizeof(smx_op), hipMemcpyDeviceToHost));
@@ -416,7 +444,6 @@ int smx_batch_run(const smx_panel *Pc, const uint8_t *windows, const int32_t *le
     if (hits) TRY_C(hipMemcpy(hits, dh, hbytes, hipMemcpyDeviceToHost));
     if (bdist) TRY_C(hipMemcpy(bdist, db, bbytes, hipMemcpyDeviceToHost));
 #undef TRY_C
-    cleanup();
     for (size_t i = 0; i < ncnt; i++) counts[i] += c[i];
     if (c[SMX_CNT_OVERFLOW]) return fail(SMX_ERR_OVERFLOW, "%llu read(s) produced more than 16 write operations",
                                          (unsigned long long)c[SMX_CNT_OVERFLOW]);

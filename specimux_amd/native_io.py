@@ -1,0 +1,111 @@
+"""Python face of the native streaming helpers in libsmx.so (include/smx.h, "Host streaming helpers"):
+FASTQ/FASTA reader -> batches, window packer, output writer.  SURVEY.md section 8(f) rows 1-2."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class Batch:
+    """One parsed batch; owns its memory on the C side."""
+
+    def __init__(self):
+        self._lib = _lib.load()
+        self.handle = C.c_void_p(self._lib.smx_batch_new())
+
+    def __len__(self):
+        return int(self._lib.smx_batch_size(self.handle))
+
+    def record(self, i):
+        """(id, sequence, quality or None) as str -- for tests and the compatibility path."""
+        pid, pseq, pqual = C.c_char_p(), C.c_void_p(), C.c_void_p()
+        nid, nseq = C.c_uint32(), C.c_uint32()
+        _lib.check(self._lib.smx_batch_record(self.handle, i, C.byref(pid), C.byref(nid), C.byref(pseq),
+                                              C.byref(pqual), C.byref(nseq)))
+        rid = C.string_at(pid, nid.value).decode("latin-1")
+        seq = C.string_at(pseq.value, nseq.value).decode("latin-1") if nseq.value else ""
+        qual = None
+        if pqual.value:
+            qual = C.string_at(pqual.value, nseq.value).decode("latin-1") if nseq.value else ""
+        return rid, seq, qual
+
+    def pack_windows(self, search_len, stride):
+        n = len(self)
+        windows = np.empty((n, stride), dtype=np.uint8)
+        lens = np.empty(n, dtype=np.int32)
+        _lib.check(self._lib.smx_pack_windows_batch(self.handle, search_len, _lib.ptr(windows), _lib.ptr(lens)))
+        return windows, lens
+
+    def close(self):
+        if self.handle:
+            self._lib.smx_batch_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Reader:
+    def __init__(self, path):
+        self._lib = _lib.load()
+        self.handle = C.c_void_p()
+        fq = C.c_int()
+        _lib.check(self._lib.smx_reader_open(path.encode(), C.byref(self.handle), C.byref(fq)))
+        self.is_fastq = bool(fq.value)
+
+    def next_batch(self, max_reads, max_bytes=0, into=None):
+        """Fill (or create) a Batch with up to max_reads records; returns None at end of file."""
+        batch = into or Batch()
+        n = C.c_uint32()
+        _lib.check(self._lib.smx_reader_next(self.handle, max_reads, max_bytes, batch.handle, C.byref(n)))
+        return batch if n.value else None
+
+    def close(self):
+        if self.handle:
+            self._lib.smx_reader_close(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _table(strings):
+    blob = "".join(strings).encode("utf-8")
+    off = np.zeros(len(strings) + 1, dtype=np.uint32)
+    if strings:
+        off[1:] = np.cumsum([len(s.encode("utf-8")) for s in strings])
+    return blob, off
+
+
+class Writer:
+    """Appends formatted records to the output tree; names come from a CompiledPanel."""
+
+    def __init__(self, output_dir, prefix, is_fastq, panel):
+        self._lib = _lib.load()
+        self._keep = [_table(panel.specimen_ids), _table(panel.pools), _table(panel.primer_names), _table(panel.barcodes)]
+        nm = _lib.Names()
+        (nm.specimens, so), (nm.pools, po), (nm.primers, pr), (nm.barcodes, bo) = self._keep
+        nm.specimen_off, nm.pool_off, nm.primer_off, nm.barcode_off = (a.ctypes.data for a in (so, po, pr, bo))
+        nm.n_specimens, nm.n_pools = len(panel.specimen_ids), len(panel.pools)
+        nm.n_primers, nm.n_barcodes = len(panel.primer_names), len(panel.barcodes)
+        self.handle = C.c_void_p()
+        _lib.check(self._lib.smx_writer_open(output_dir.encode(), (prefix or "").encode(), 1 if is_fastq else 0,
+                                             C.byref(nm), C.byref(self.handle)))
+
+    def write(self, batch, ops, extra):
+        ops = np.ascontiguousarray(ops)
+        extra = np.ascontiguousarray(extra)
+        _lib.check(self._lib.smx_writer_write(self.handle, batch.handle, _lib.ptr(ops), len(ops),
+                                              _lib.ptr(extra) if len(extra) else None, len(extra)))
+
+    def close(self):
+        if self.handle:
+            h, self.handle = self.handle, None
+            _lib.check(self._lib.smx_writer_close(h))

@@ -159,21 +159,50 @@ def iter_batches(seq_records, batch_size: int, max_seqs: int, all_seqs: bool):
         done += len(batch)
 
 
-def _run(args, to_files: bool):
-    from .demultiplex import process_sequences   # needs libsmx.so: import late so --help works without it
+def _load(args):
     registry = read_primers_file(args.primer_file)
     specimens = read_specimen_file(args.specimen_file, registry)
     specimens.validate()
     parameters = setup_match_parameters(args, specimens)
+    prefilter = None
+    if not args.disable_prefilter:
+        prefilter = BloomPrefilter(barcodes_for_bloom_prefilter(specimens), parameters.max_dist_index)
+    return specimens, parameters, prefilter
+
+
+def _finish(total, matched, start):
+    if total > 0:
+        logging.info(f"Processed {total:,} sequences, match rate: {matched / total:.1%}")
+    logging.info(f"Elapsed time: {timeit.default_timer() - start:.2f} seconds")
+
+
+def _run_native(args):
+    """`-F`: native reader -> GPU -> native writer, overlapped (specimux_amd/pipeline.py)."""
+    from .demultiplex import compiled_panel   # needs libsmx.so: import late so --help works without it
+    from .io_utils import detect_file_format
+    from .pipeline import run_streaming
+    specimens, parameters, prefilter = _load(args)
+    args.isfastq = detect_file_format(args.sequence_file) == "fastq"
+    create_output_files(args, specimens)
+    start = timeit.default_timer()
+    panel = compiled_panel(specimens, parameters, args, prefilter)
+    total, matched, _counts, _fq = run_streaming(args.sequence_file, panel, args.output_dir, args.output_file_prefix,
+                                                 start_seq=args.start_seq, num_seqs=args.num_seqs)
+    _finish(total, matched, start)
+    cleanup_empty_directories(args.output_dir)
+    cleanup_locks(args.output_dir)
+
+
+def _run_records(args, to_files: bool):
+    """Record-object path (stdout mode, --color): Python parser + process_sequences + OutputManager."""
+    from .demultiplex import process_sequences
+    specimens, parameters, prefilter = _load(args)
     seq_records = open_sequence_file(args.sequence_file, args)
     create_output_files(args, specimens)
     start = timeit.default_timer()
     if args.start_seq > 1:
         for _ in itertools.islice(seq_records, args.start_seq - 1):
             pass
-    prefilter = None
-    if not args.disable_prefilter:
-        prefilter = BloomPrefilter(barcodes_for_bloom_prefilter(specimens), parameters.max_dist_index)
     total = matched = 0
     manager = OutputManager(args.output_dir, args.output_file_prefix, args.isfastq) if to_files else None
     try:
@@ -188,9 +217,7 @@ def _run(args, to_files: bool):
     finally:
         if manager:
             manager.close()
-    if total > 0:
-        logging.info(f"Processed {total:,} sequences, match rate: {matched / total:.1%}")
-    logging.info(f"Elapsed time: {timeit.default_timer() - start:.2f} seconds")
+    _finish(total, matched, start)
     if to_files:
         cleanup_empty_directories(args.output_dir)
         cleanup_locks(args.output_dir)
@@ -199,9 +226,11 @@ def _run(args, to_files: bool):
 def specimux_mp(args):
     """File-output entry (`-F`).  The reference forks a worker pool here; the GPU path needs no host
     parallelism for the matching itself."""
-    _run(args, to_files=True)
+    if getattr(args, "diagnostics", None):
+        raise NotImplementedError("trace logging (-d) is not available on the GPU path yet")
+    _run_native(args)
 
 
 def specimux(args):
     """stdout entry (no `-F`)."""
-    _run(args, to_files=False)
+    _run_records(args, to_files=False)

@@ -316,3 +316,63 @@ def test_counts_allreduce_single_rank(lib):
     torch.cuda.synchronize()
     assert t.cpu().tolist() == list(range(20))
     lib.smx_comm_destroy(comm)
+
+
+# ------------------------------------------------------------------ end to end through the CLI (native reader/writer)
+def _oracle_tree(pf, sf, seqfile, **kw):
+    tree, total, matched = __import__("oracle.specimux_oracle", fromlist=["x"]).run_files(pf, sf, seqfile, **kw)
+    return {k: sorted(v) for k, v in tree.items()}, total, matched
+
+
+@pytest.mark.parametrize("variant", ["plain", "gz", "window", "fasta", "tails_prefix"])
+def test_cli_end_to_end_synthetic(lib, c2, tmp_path, variant):
+    import gzip
+    import shutil
+    from specimux_amd import cli, synth
+    pan, (pf, sf) = c2
+    rs = synth.make_reads(pan, 1200, 4242, windows_only=False)
+    fq = tmp_path / "reads.fastq"
+    rs.write_fastq(str(fq))
+    seqfile, extra_args, okw = str(fq), [], {}
+    if variant == "gz":
+        seqfile = str(tmp_path / "reads.fastq.gz")
+        with open(fq, "rb") as a, gzip.open(seqfile, "wb") as b:
+            shutil.copyfileobj(a, b)
+    elif variant == "window":
+        extra_args = ["-n", "101,500"]
+    elif variant == "fasta":
+        seqfile = str(tmp_path / "reads.fasta")
+        with open(seqfile, "w") as fh:
+            for i, s in enumerate(rs.reads):
+                fh.write(f">read{i:07d} synthetic\n{s[:70]}\n{s[70:]}\n")
+    elif variant == "tails_prefix":
+        extra_args = ["--trim", "tails", "-P", "x_"]
+        okw = {"trim": "tails"}
+    out = tmp_path / "out"
+    cli.main(["specimux", pf, sf, seqfile, "-F", "-O", str(out)] + extra_args)
+    got = read_expected_tree(str(out)) if variant != "fasta" else None
+    exp, total, matched = _oracle_tree(pf, sf, seqfile, **okw)
+    if variant == "window":
+        from oracle import specimux_oracle as O
+        panel = O.load_panel(pf, sf)
+        recs, _ = O.read_sequences(seqfile)
+        ops, total, matched = O.process_sequences(recs[100:600], O.setup_params(panel), panel)
+        exp = {}
+        for op in ops:
+            for p in O.op_path(op):
+                exp.setdefault(p, []).append(O.op_record(op))
+        exp = {k: sorted(v) for k, v in exp.items()}
+    if variant == "tails_prefix":
+        exp = {"/".join(k.split("/")[:-1] + ["x_" + k.split("/")[-1]]): v for k, v in exp.items()}
+    if variant == "fasta":
+        import os
+        got = {}
+        for dirpath, _d, files in os.walk(out):
+            for fn in files:
+                if fn.endswith(".fasta") and not fn.startswith("primers"):
+                    lines = open(os.path.join(dirpath, fn)).read().split("\n")
+                    got[os.path.relpath(os.path.join(dirpath, fn), out)] = sorted(
+                        "\n".join(lines[i:i + 2]) + "\n" for i in range(0, len(lines) - 1, 2))
+    assert got == exp
+    log = (out / "log.txt").read_text()
+    assert f"Processed {total:,} sequences, match rate: {matched / total:.1%}" in log

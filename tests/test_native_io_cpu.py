@@ -1,0 +1,152 @@
+"""Native streaming helpers (libsmx.so host code, no GPU): reader vs the Python parser, window packer, and the
+output writer vs the oracle's tree -- the writer is fed smx_op records built from the ORACLE's write operations,
+so formatting / orientation / trimming / paths are checked without a device."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, read_expected_tree
+from oracle import specimux_oracle as O
+from parity_utils import Both
+
+P, S = f"{GOLDEN}/primers.fasta", f"{GOLDEN}/specimens.txt"
+
+
+def _all_records(path, chunk=1000):
+    from specimux_amd.native_io import Reader
+    r = Reader(path)
+    out = []
+    while True:
+        b = r.next_batch(chunk)
+        if b is None:
+            break
+        out += [b.record(i) for i in range(len(b))]
+    return out, r.is_fastq
+
+
+def test_reader_equals_python_parser_on_golden():
+    from specimux_amd.io_utils import open_sequence_file
+    from parity_utils import make_args
+    for name in ("sequences.fastq", "sequences_rc.fastq"):
+        got, fq = _all_records(f"{GOLDEN}/{name}", chunk=7)
+        exp = [(r.id, r.seq, r.quality_string) for r in open_sequence_file(f"{GOLDEN}/{name}", make_args())]
+        assert fq and got == exp and len(got) == 40
+
+
+def test_reader_formats(tmp_path):
+    from specimux_amd.io_utils import open_sequence_file
+    from parity_utils import make_args
+    cases = {
+        "wrapped.fq": "@r1 x y\nACGT\nAC\n+\n@III\nII\n@r2\nGG\n+r2\n@@\n\n@r3\n\n+\n\n",
+        "crlf.fastq": "@a b\r\nACGT\r\n+\r\nIIII\r\n@c\r\nTT\r\n+\r\n##\r\n",
+        "plain.fasta": ">a desc\nACG T\nTT\n\n>b\nGGA\n>empty\n>c\nA\n",
+        "noext": "@q\nAC\n+\nII\n",
+        "noext_fa": ">q\nAC\n",
+    }
+    for name, text in cases.items():
+        path = tmp_path / name
+        path.write_text(text)
+        gz = tmp_path / (name + ".gz")
+        with gzip.open(gz, "wt") as fh:
+            fh.write(text)
+        for pth in (path, gz):
+            got, fq = _all_records(os.fspath(pth), chunk=2)
+            a = make_args()
+            exp = [(r.id, r.seq, r.quality_string) for r in open_sequence_file(os.fspath(pth), a)]
+            assert got == exp, (name, got, exp)
+            assert fq == a.isfastq
+    bad = tmp_path / "bad.fastq"
+    bad.write_text("@r\nACGT\n+\nII\n")
+    from specimux_amd import _lib
+    with pytest.raises(_lib.SmxError):
+        _all_records(os.fspath(bad))
+
+
+def test_pack_windows_batch_equals_pack_windows():
+    from specimux_amd.demultiplex import compiled_panel, concat_records
+    from specimux_amd.io_utils import SeqRecord
+    from specimux_amd.native_io import Reader
+    both = Both(P, S)
+    cp = compiled_panel(both.specimens, both.parameters, both.args, both.prefilter)
+    b = Reader(f"{GOLDEN}/sequences.fastq").next_batch(100)
+    w1, l1 = b.pack_windows(cp.search_len, cp.window_stride)
+    recs = [SeqRecord(s, i, i, q) for i, s, q in (b.record(k) for k in range(len(b)))]
+    bases, offsets, _ = concat_records(recs)
+    w2, l2 = cp.pack_windows(bases, offsets)
+    assert np.array_equal(w1, w2) and np.array_equal(l1, l2)
+
+
+def _ops_from_oracle(cp, oracle_ops, n_reads, id_to_index):
+    """Oracle write operations -> (ops[n_reads], extra[]) smx_op arrays."""
+    from specimux_amd import _lib
+    ops = np.zeros(n_reads, dtype=_lib.OP_DTYPE)
+    ops["rtype"] = _lib.R_FILTERED
+    extra = []
+    seen = set()
+    for op in oracle_ops:
+        rec = np.zeros(1, dtype=_lib.OP_DTYPE)[0]
+        i = id_to_index[op.seq_id]
+        rec["read"] = i
+        rec["sample"] = cp.specimen_ids.index(op.sample_id) if op.sample_id in cp.specimen_ids else -1
+        rec["trim_start"], rec["trim_end"] = op.trim
+        rec["pool"] = cp.pools.index(op.pool) if op.pool in cp.pools else -1
+        rec["p1"] = cp.primer_names.index(op.p1) if op.p1 in cp.primer_names else -1
+        rec["p2"] = cp.primer_names.index(op.p2) if op.p2 in cp.primer_names else -1
+        rec["barcode"] = cp.barcodes.index(op.sample_id.split("_")[-1]) if op.sample_id.startswith("barcode_") else -1
+        rec["dist"] = [(-1 if d == "X" else int(d)) for d in op.code.split(",")]
+        rec["rtype"] = op.rtype
+        rec["flags"] = _lib.OPF_REVERSE if op.reverse else 0
+        if i in seen:
+            extra.append(rec)
+        else:
+            seen.add(i)
+            ops[i] = rec
+    return ops, (np.array(extra, dtype=_lib.OP_DTYPE) if extra else np.zeros(0, dtype=_lib.OP_DTYPE))
+
+
+@pytest.mark.parametrize("seqfile", ["sequences.fastq", "sequences_rc.fastq"])
+def test_writer_tree_from_oracle_ops_equals_expected_output(tmp_path, seqfile):
+    from specimux_amd.demultiplex import compiled_panel
+    from specimux_amd.native_io import Reader, Writer
+    both = Both(P, S)
+    cp = compiled_panel(both.specimens, both.parameters, both.args, both.prefilter)
+    reads, _ = O.read_sequences(f"{GOLDEN}/{seqfile}")
+    oracle_ops, _, _ = O.process_sequences(reads, both.opar, both.opanel)
+    batch = Reader(f"{GOLDEN}/{seqfile}").next_batch(1000)
+    ops, extra = _ops_from_oracle(cp, oracle_ops, len(reads), {r[0]: i for i, r in enumerate(reads)})
+    w = Writer(os.fspath(tmp_path / "out"), "", True, cp)
+    w.write(batch, ops, extra)
+    w.close()
+    got = read_expected_tree(os.fspath(tmp_path / "out"))
+    tree = {}
+    for op in oracle_ops:
+        for p in O.op_path(op):
+            tree.setdefault(p, []).append(O.op_record(op))
+    assert got == {k: sorted(v) for k, v in tree.items()}
+    if seqfile == "sequences.fastq":
+        assert got == read_expected_tree(f"{GOLDEN}/expected_output")
+
+
+def test_writer_prefix_fasta_and_safe_names(tmp_path):
+    from specimux_amd import _lib
+    from specimux_amd.native_io import Reader, Writer
+
+    class FakePanel:
+        specimen_ids = ["we ird/na:me", "ok-1"]
+        pools, primer_names, barcodes = ["P1"], ["F", "R"], ["ACGT"]
+    fa = tmp_path / "in.fasta"
+    fa.write_text(">r1 d\nAACCGGTT\n>r2\nACGTACGT\n")
+    batch = Reader(os.fspath(fa)).next_batch(10)
+    ops = np.zeros(2, dtype=_lib.OP_DTYPE)
+    ops[0] = (0, 2, 6, 0, 0, 1, -1, [0, 1, 2, 0], _lib.R_DEREP_FULL, _lib.OPF_REVERSE, 1, 0)
+    ops[1] = (-1, 0, 8, -1, -1, 1, 0, [-1, -1, 3, 1], _lib.R_PARTIAL_REV, 0, 1, 1)
+    w = Writer(os.fspath(tmp_path / "o"), "pre_", False, FakePanel)
+    w.write(batch, ops, np.zeros(0, dtype=_lib.OP_DTYPE))
+    w.close()
+    # reverse complement of AACCGGTT is AACCGGTT; [2:6] = CCGG
+    assert (tmp_path / "o/full/P1/F-R/pre_we_ird_na_me.fasta").read_text() == ">r1 0,1,2,0 pool=P1 primers=F+R we ird/na:me\nCCGG\n"
+    assert (tmp_path / "o/full/P1/pre_we_ird_na_me.fasta").exists()
+    assert (tmp_path / "o/partial/unknown/unknown-R/pre_barcode_rev_ACGT.fasta").read_text() == \
+        ">r2 X,X,3,1 pool=unknown primers=unknown+R barcode_rev_ACGT\nACGTACGT\n"

@@ -113,7 +113,7 @@ struct smx_panel {
     smx::DevPanel hp;                 // scalar fields valid; pointers filled at upload
     std::vector<unsigned char> blob;  // host image of the device allocation
     size_t o_ppeq, o_prpeq, o_bpeq, o_lut, o_pm, o_pk, o_pdir, o_pfidx, o_pbc_off, o_pbc, o_bm, o_pair_f, o_pair_r,
-        o_pair_pool, o_pairhead, o_spec_next, o_p1m, o_p2m, o_spec_pool;
+        o_pair_pool, o_pairhead, o_spec_next, o_p1m, o_p2m, o_spec_pool, o_bsre;
     int use64 = 0;
     int R = 0;          // lean mode tile (no per-barcode slots)
     size_t lds = 0;
@@ -225,6 +225,22 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
         for (int c = 0; c < 16; c++) bpeq[b * 16 + c] = (unsigned)t[c];
         bm[b] = m;
     }
+    // bit-sliced barcode tables: usable when every barcode has the same length <= 16 and k <= 7
+    const int MBWh = (maxB + 31) / 32;
+    bool bs_ok = d->k_index <= 7 && !getenv("SMX_NO_BITSLICE");
+    for (int b = 0; b < NB; b++) if (bm[b] != bm[0] || bm[b] > 16) bs_ok = false;
+    std::vector<unsigned> bsre((size_t)NP * 16 * 16 * MBWh, 0u);
+    if (bs_ok)
+        for (int p = 0; p < NP; p++)
+            for (int li = pbc_off[p]; li < pbc_off[p + 1]; li++) {
+                int gb = pbc[li], bi = li - pbc_off[p];
+                for (int row = 0; row < bm[gb]; row++)
+                    for (int c = 0; c < 16; c++)
+                        if ((bpeq[gb * 16 + c] >> row) & 1u)
+                            bsre[(((size_t)p * 16 + row) * 16 + c) * MBWh + (bi >> 5)] |= 1u << (bi & 31);
+            }
+    h.bs_ok = bs_ok ? 1 : 0;
+    h.bs_m = bm[0];
     if (h.pfmin != 0 && h.pfmin < 2) { delete P; return fail(SMX_ERR_UNSUPPORTED, "prefilter min length %d < 2: disable the prefilter", h.pfmin); }
     if (h.bmax + h.kidx > 200) { delete P; return fail(SMX_ERR_UNSUPPORTED, "barcode length + k too large"); }
     h.maxB = maxB;
@@ -264,6 +280,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     P->o_pair_f = blob_add(B, pair_f); P->o_pair_r = blob_add(B, pair_r); P->o_pair_pool = blob_add(B, pair_pool);
     P->o_pairhead = blob_add(B, pairhead); P->o_spec_next = blob_add(B, spec_next);
     P->o_p1m = blob_add(B, p1m); P->o_p2m = blob_add(B, p2m); P->o_spec_pool = blob_add(B, spec_pool);
+    P->o_bsre = blob_add(B, bsre);
 
     P->use64 = maxm > 32 ? 1 : 0;
     // tile size: largest R in {64, 32, ...} whose LDS image lets 4 workgroups share a CU's 160 KiB
@@ -275,7 +292,8 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     const int npmeta = 5 * NP + 1 + h.n_pbc + NB + 3 * NPAIR;
     for (int slots = 0; slots < 2; slots++)
         for (int R = rmax; R >= 1; R >>= 1) {
-            size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, slots);
+            size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, slots,
+                                              h.bs_ok);
             if (need <= budget || R == 1) {
                 if (slots) { P->R_slots = R; P->lds_slots = need; } else { P->R = R; P->lds = need; }
                 break;
@@ -360,6 +378,7 @@ static int ensure_device(smx_panel *P) {
     h.pairhead = (const int *)(b + P->o_pairhead); h.spec_next = (const int *)(b + P->o_spec_next);
     h.spec_p1m = (const unsigned long long *)(b + P->o_p1m); h.spec_p2m = (const unsigned long long *)(b + P->o_p2m);
     h.spec_pool = (const int *)(b + P->o_spec_pool);
+    h.bs_re = (const unsigned *)(b + P->o_bsre);
     if (std::max(P->lds, P->lds_slots) > 64 * 1024) {
         int rc = smx_set_demux_lds_limit(P->use64, std::max(P->lds, P->lds_slots));
         if (rc != 0) return fail(SMX_ERR_DEVICE, "cannot raise the dynamic LDS limit to %zu bytes", std::max(P->lds, P->lds_slots));

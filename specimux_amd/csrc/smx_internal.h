@@ -35,6 +35,10 @@ struct DevPanel {
     const int *spec_next;                 // chain in file order
     const unsigned long long *spec_p1m, *spec_p2m;
     const int *spec_pool;
+    // bit-sliced barcode scan (lean mode): all barcodes one length bs_m <= 16, k <= 7.
+    // bs_re[((p * 16 + row) * 16 + code) * MBW + w] = bitmask over primer p's barcode list: barcode_rc[row] eq code
+    int bs_ok, bs_m;
+    const unsigned *bs_re;
     unsigned long long *dbg_phase;        // SMX_PHASE_TIMING=1: [grid][16] cycle sums per phase (diagnostic build-in)
 };
 
@@ -46,7 +50,7 @@ int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t 
                      uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts, smx_hit *d_hits, int8_t *d_bdist,
                      unsigned *d_tile_counter, int use_slots);
 size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta, int kidx,
-                           int slots);
+                           int slots, int bs);
 int smx_set_demux_lds_limit(int use64, size_t bytes);
 int smx_query_occupancy(int use64, size_t lds_bytes, int *blocks_per_cu);
 int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,

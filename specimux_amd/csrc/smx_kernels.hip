@@ -96,13 +96,14 @@ static_assert(sizeof(HitL) == 20, "HitL layout");
 #define SMX_MAX_EMIT 16
 
 struct TileLayout {   // byte offsets into dynamic LDS
-    int ppeq, prpeq, bpeq, lut, pmeta, codes, namask, lens, ocnt, hits, masks, tiem, bres, dmask, ents, offsA, offsB, queue, emit, opsL, aggr,
+    int ppeq, prpeq, bpeq, bsre, lut, pmeta, codes, namask, lens, ocnt, hits, masks, tiem, bres, dmask, ents, offsA, offsB, queue, emit, opsL, aggr,
         total;
     int CS;      // bytes per code row (odd number of dwords: conflict-free column reads across rows)
     int lNPs, lNBs;  // their log2
     int NPs, NBs;  // power-of-two strides of the transposed Peq tables: entry [code][pattern]
     int G, logG;   // barcode slots per (hit) group: power of two >= maxB
     int MBW;     // tie-mask words per hit
+    int BSP;     // bit-sliced table: words per primer
     int CAPH, CAPE;  // hits / (hit, location) entries processed per barcode round
 };
 
@@ -118,7 +119,7 @@ static_assert(sizeof(EntL) == 8, "EntL layout");
 
 template <typename PW>
 __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, int maxB, int need_starts,
-                                                    int npmeta, int kidx, int slots) {
+                                                    int npmeta, int kidx, int slots, int bs) {
     TileLayout t;
     int H = 2 * NP, MW = (S + 31) / 32;
     t.CS = 4 * (((S + 3) / 4) | 1);
@@ -138,6 +139,8 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.ppeq = o;  o += t.NPs * 16 * (int)sizeof(PW);
     t.prpeq = o; o += (need_starts ? t.NPs * 16 * (int)sizeof(PW) : 0);
     t.bpeq = o;  o += t.NBs * 16 * 4;
+    t.BSP = (16 * 16 + 4) * t.MBW;              // words per primer in the bit-sliced table (+4: bank skew)
+    t.bsre = o;  o += (bs && !slots) ? NP * t.BSP * 4 : 0;
     t.lut = o;   o += 512;
     t.pmeta = o; o += npmeta * 4;
     o = (o + 15) & ~15;
@@ -196,6 +199,67 @@ __device__ __forceinline__ int nth_location(const unsigned *mrow, int MW, int js
         seen += pc;
     }
     return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bit-sliced SHW scan: ONE lane aligns up to 32 barcodes (one word of the primer's barcode list) against one
+// target at once.  Bit b of every word belongs to barcode b.  Per DP cell (row i = barcode position, column c =
+// target position) the unit-cost recurrence on the vertical / horizontal deltas in {-1,0,+1} is
+//     Z = Eq | Mh_in | Mv_in                       (the cell's minimum is the diagonal value)
+//     Ph_out = Mv_in | ~(Z | Pv_in)   Mh_out = Pv_in & Z      (bottom edge, handed to the next column)
+//     Pv_out = Mh_in | ~(Z | Ph_in)   Mv_out = Ph_in & Z      (right edge, handed to the next row)
+// with SHW boundaries D[0][j] = j, D[i][0] = i.  D[m][c] is kept as a bit-sliced 5-bit counter; seen[d] collects
+// the barcodes whose last-row score equalled d (<= k) at some column: exactly what the per-hit distance-level
+// bitmasks of the lean summary need (the lowest non-empty level is the best distance, its bits are the tie set).
+__device__ __forceinline__ void bitsliced_shw(const unsigned *re, int MBW, const unsigned char *cw, int ncol, int m,
+                                              int kidx, unsigned (&seen)[8]) {
+    unsigned Pv[16], Mv[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { Pv[i] = ~0u; Mv[i] = 0u; }
+    unsigned s0 = (m & 1) ? ~0u : 0u, s1 = (m & 2) ? ~0u : 0u, s2 = (m & 4) ? ~0u : 0u, s3 = (m & 8) ? ~0u : 0u,
+             s4 = (m & 16) ? ~0u : 0u;
+#pragma unroll
+    for (int d = 0; d < 8; d++) seen[d] = 0u;
+    const int ncols = m + kidx, rs = 16 * MBW;
+    for (int c = 0; c < ncols; c++) {
+        const unsigned code = c < ncol ? (unsigned)cw[c] : 15u;   // past the window: code 15 matches nothing
+        const unsigned *rc = re + code * MBW;
+        unsigned Ph = ~0u, Mh = 0u;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (i < m) {
+                const unsigned Eq = rc[i * rs];
+                const unsigned Z = Eq | Mh | Mv[i];
+                const unsigned nPh = Mv[i] | ~(Z | Pv[i]);
+                const unsigned nMh = Pv[i] & Z;
+                const unsigned nPv = Mh | ~(Z | Ph);
+                const unsigned nMv = Ph & Z;
+                Pv[i] = nPv; Mv[i] = nMv; Ph = nPh; Mh = nMh;
+            }
+        }
+        {   // score += Ph - Mh (disjoint masks), ripple through the five planes
+            unsigned cy = Ph, t;
+            t = s0 & cy; s0 ^= cy; cy = t;
+            t = s1 & cy; s1 ^= cy; cy = t;
+            t = s2 & cy; s2 ^= cy; cy = t;
+            t = s3 & cy; s3 ^= cy; cy = t;
+            s4 ^= cy;
+            unsigned bw = Mh;
+            t = ~s0 & bw; s0 ^= bw; bw = t;
+            t = ~s1 & bw; s1 ^= bw; bw = t;
+            t = ~s2 & bw; s2 ^= bw; bw = t;
+            t = ~s3 & bw; s3 ^= bw; bw = t;
+            s4 ^= bw;
+        }
+        if (c >= m - kidx - 1) {   // a score <= k needs at least m - k consumed columns
+            const unsigned live = c < ncol ? ~0u : 0u;
+            const unsigned hi = ~(s4 | s3) & live;
+#pragma unroll
+            for (int d = 0; d < 8; d++)
+                if (d <= kidx)
+                    seen[d] |= hi & ((d & 1) ? s0 : ~s0) & ((d & 2) ? s1 : ~s1) & ((d & 4) ? s2 : ~s2);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -603,10 +667,12 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
     const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
     const int n_pbc = P->n_pbc, NPAIR = P->NPAIR;
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
-    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta, P->kidx, use_slots);
+    const int use_bs = (P->bs_ok && !use_slots) ? 1 : 0;
+    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta, P->kidx, use_slots, P->bs_ok);
     PW *ppeq = (PW *)(lds + T.ppeq);        // [code][primer], stride NPs
     PW *prpeq = (PW *)(lds + T.prpeq);
     unsigned *bpeq = (unsigned *)(lds + T.bpeq);   // [code][barcode], stride NBs
+    unsigned *bsre = (unsigned *)(lds + T.bsre);   // bit-sliced table [primer][row][code][word] (lean mode)
     unsigned char *lut = lds + T.lut;
     unsigned char *codes = lds + T.codes;
     unsigned *namask = (unsigned *)(lds + T.namask);
@@ -634,6 +700,11 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
         if (P->need_starts) prpeq[c * NPs + p] = (PW)P->prpeq[i];
     }
     for (int i = tid; i < NB * 16; i += 256) bpeq[(i & 15) * NBs + (i >> 4)] = P->bpeq[i];
+    if (use_bs)
+        for (int i = tid; i < NP * 16 * 16 * T.MBW; i += 256) {
+            int p = i / (256 * T.MBW);
+            bsre[p * T.BSP + (i - p * 256 * T.MBW)] = P->bs_re[i];
+        }
     for (int i = tid; i < 512; i += 256) lut[i] = P->lut[i];
     int *pmeta = (int *)(lds + T.pmeta);
     LPanel LP;
@@ -913,6 +984,22 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
             __syncthreads();
             STAMP(3);
 
+            // 3b (lean, uniform barcode length): bit-sliced scan, one lane per (entry, 32-barcode word)
+            if (use_bs) {
+                const int bsm = P->bs_m;
+                for (int item = tid; item < nE * MBW; item += 256) {
+                    const int ei = item / MBW, w = item - ei * MBW;
+                    const EntL en = ents[ei];
+                    if (!en.ok) continue;
+                    const int hh = en.hit, h = hh % H, p = h >> 1, X = h & 1, r = hh / H;
+                    unsigned seen[8];
+                    bitsliced_shw(bsre + p * T.BSP + w, MBW, codes + (r * 2 + X) * CS + en.tj0, en.ncol, bsm, kidx, seen);
+                    unsigned *dm = dmask + ((en.slot >> logG) * (kidx + 1)) * MBW + w;
+#pragma unroll
+                    for (int d = 0; d < 8; d++)
+                        if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
+                }
+            } else
             // 3b: barcode scan, one lane per (entry, barcode slot)
             for (int item = tid; item < (nE << logG); item += 256) {
                 const EntL en = ents[item >> logG];
@@ -1177,9 +1264,9 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
 }
 
 extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta,
-                                      int kidx, int slots) {
-    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots).total
-                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots).total;
+                                      int kidx, int slots, int bs) {
+    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs).total
+                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs).total;
 }
 
 extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {

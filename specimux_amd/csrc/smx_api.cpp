@@ -126,7 +126,8 @@ struct smx_panel {
     int blocks_per_cu = 1;
     std::mutex ws_mutex;                     // smx_batch_run is serialised per panel (one workspace)
     DevBuf ws[8];                            // windows, lens, ops, extra, n_extra, counts, hits, bdist
-    unsigned *d_tile_counter = nullptr;      // dynamic tile queue head (zeroed on the stream before each launch)
+    DevBuf defer;                            // hit-table dumps of the reads deferred to the general scorer
+    unsigned *d_tile_counter = nullptr;      // [0] dynamic tile queue head, [1] deferred-read counter (zeroed on the stream before each launch)
     unsigned long long *d_phase = nullptr;   // SMX_PHASE_TIMING diagnostic
     int phase_grid = 0;
 };
@@ -324,6 +325,7 @@ void smx_panel_destroy(smx_panel *P) {
     if (P->d_blob) (void)hipFree(P->d_blob);
     if (P->d_tile_counter) (void)hipFree(P->d_tile_counter);
     for (auto &b : P->ws) b.release();
+    P->defer.release();
     delete P;
 }
 
@@ -414,10 +416,16 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     const int use_slots = (P->hp.trim == SMX_TRIM_TAILS || d_hits || d_bdist || getenv("SMX_FORCE_SLOTS")) ? 1 : 0;
     const int R = use_slots ? P->R_slots : P->R;
     const size_t lds = use_slots ? P->lds_slots : P->lds;
+    // two-kernel build only: worst case every read is deferred, one record each (grow-only)
+    if (smx_deferred_rec_bytes(P->hp.NP, P->hp.maxB) > 0) {
+        hipError_t de = P->defer.ensure((size_t)n_reads * smx_deferred_rec_bytes(P->hp.NP, P->hp.maxB));
+        if (de != hipSuccess) return fail(SMX_ERR_DEVICE, "deferred-read buffer: %s", hipGetErrorString(de));
+    }
     uint32_t tiles = (n_reads + R - 1) / R;
     int grid = (int)std::min<uint32_t>(tiles, (uint32_t)(P->n_cu * P->blocks_per_cu));
     int e = smx_launch_demux(&P->hp, P->use64, R, grid, lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
-                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, P->d_tile_counter, use_slots);
+                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, P->d_tile_counter, use_slots,
+                             (unsigned char *)P->defer.p);
     if (e != 0) return fail(SMX_ERR_DEVICE, "demux kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return SMX_OK;
 }
@@ -454,6 +462,11 @@ int smx_batch_run(const smx_panel *Pc, const uint8_t *windows, const int32_t *le
                               (uint32_t *)dn, (uint64_t *)dc, (smx_hit *)dh, (int8_t *)db);
     if (rc) return rc;
     TRY_C(hipDeviceSynchronize());
+    if (getenv("SMX_DEBUG")) {
+        unsigned tc[2] = {0, 0};
+        (void)hipMemcpy(tc, P->d_tile_counter, 8, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[smx] batch of %u reads: %u deferred to the general scorer\n", n_reads, tc[1]);
+    }
     std::vector<uint64_t> c(ncnt);
     TRY_C(hipMemcpy(ops, dop, (size_t)n_reads * sizeof(smx_op), hipMemcpyDeviceToHost));
     TRY_C(hipMemcpy(n_extra, dn, 4, hipMemcpyDeviceToHost));

@@ -94,9 +94,22 @@ struct HitL {
 static_assert(sizeof(HitL) == 20, "HitL layout");
 
 #define SMX_MAX_EMIT 16
+// SMX_DEFER=1 builds the two-kernel variant: the hot kernel dumps the hit table of reads that need the general
+// scorer (ties, several best candidates) and score_deferred_kernel finishes them.  Measured on MI355X: the hot
+// kernel gets 10 % shorter but the deferred kernel is one long dependent chain of global loads (0.25 ms for 0.1 %
+// of the reads), so the single-kernel build (0) is the default.
+#ifndef SMX_DEFER
+#define SMX_DEFER 0
+#endif
+
+// Deferred reads (general scorer): record = int read, L, ori, pad; HitL hits[H]; unsigned tiem[H * MBW]
+__host__ __device__ inline int deferred_rec_bytes(int H, int MBW) {
+    return (16 + H * (int)sizeof(HitL) + H * MBW * 4 + 15) & ~15;
+}
+
 
 struct TileLayout {   // byte offsets into dynamic LDS
-    int ppeq, prpeq, bpeq, bsre, lut, pmeta, codes, namask, lens, ocnt, hits, masks, tiem, bres, dmask, ents, offsA, offsB, queue, emit, opsL, aggr,
+    int tacc, ppeq, prpeq, bpeq, bsre, lut, pmeta, codes, namask, lens, ocnt, hits, masks, tiem, bres, dmask, ents, offsA, offsB, queue, emit, opsL, aggr,
         total;
     int CS;      // bytes per code row (odd number of dwords: conflict-free column reads across rows)
     int lNPs, lNBs;  // their log2
@@ -136,6 +149,7 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.CAPH = dense < fit ? dense : (fit < 1 ? 1 : fit);
     t.CAPE = t.CAPH + t.CAPH / 4 < 320 ? 320 : t.CAPH + t.CAPH / 4;   // >= 256 = max locations of one hit (progress)
     int o = 0;
+    t.tacc = o;  o += 11 * 8 + 8;
     t.ppeq = o;  o += t.NPs * 16 * (int)sizeof(PW);
     t.prpeq = o; o += (need_starts ? t.NPs * 16 * (int)sizeof(PW) : 0);
     t.bpeq = o;  o += t.NBs * 16 * 4;
@@ -211,15 +225,16 @@ __device__ __forceinline__ int nth_location(const unsigned *mrow, int MW, int js
 // with SHW boundaries D[0][j] = j, D[i][0] = i.  D[m][c] is kept as a bit-sliced 5-bit counter; seen[d] collects
 // the barcodes whose last-row score equalled d (<= k) at some column: exactly what the per-hit distance-level
 // bitmasks of the lean summary need (the lowest non-empty level is the best distance, its bits are the tie set).
+template <int KL>   // KL = number of distance levels kept (k + 1 <= KL): 4 or 8
 __device__ __forceinline__ void bitsliced_shw(const unsigned *re, int MBW, const unsigned char *cw, int ncol, int m,
-                                              int kidx, unsigned (&seen)[8]) {
+                                              int kidx, unsigned (&seen)[KL]) {
     unsigned Pv[16], Mv[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) { Pv[i] = ~0u; Mv[i] = 0u; }
     unsigned s0 = (m & 1) ? ~0u : 0u, s1 = (m & 2) ? ~0u : 0u, s2 = (m & 4) ? ~0u : 0u, s3 = (m & 8) ? ~0u : 0u,
              s4 = (m & 16) ? ~0u : 0u;
 #pragma unroll
-    for (int d = 0; d < 8; d++) seen[d] = 0u;
+    for (int d = 0; d < KL; d++) seen[d] = 0u;
     const int ncols = m + kidx, rs = 16 * MBW;
     for (int c = 0; c < ncols; c++) {
         const unsigned code = c < ncol ? (unsigned)cw[c] : 15u;   // past the window: code 15 matches nothing
@@ -255,7 +270,7 @@ __device__ __forceinline__ void bitsliced_shw(const unsigned *re, int MBW, const
             const unsigned live = c < ncol ? ~0u : 0u;
             const unsigned hi = ~(s4 | s3) & live;
 #pragma unroll
-            for (int d = 0; d < 8; d++)
+            for (int d = 0; d < KL; d++)
                 if (d <= kidx)
                     seen[d] |= hi & ((d & 1) ? s0 : ~s0) & ((d & 2) ? s1 : ~s1) & ((d & 4) ? s2 : ~s2);
         }
@@ -498,10 +513,76 @@ __device__ inline bool cand_has_specimen(const ReadCtx &c, const CandView &v, in
     return false;
 }
 
-__device__ inline void score_read(Emitter &E, int ori) {
+// Fast scorer of the hot kernel: handles "no candidate" and "exactly one candidate at the best score, no
+// barcode tie".  Every dereplication group then has one member and the reference's machinery reduces to a
+// single emission.  Returns false for everything else (several best candidates, ties): those reads are
+// deferred to score_deferred_kernel, which runs score_general on a dump of the read's hit table.
+__device__ inline bool score_fast(Emitter &E, int ori) {
     const ReadCtx &c = *E.c;
     const DevPanel *P = c.P;
-    // ---- select_best_matches (demultiplex.py:216-259)
+    // ---- select_best_matches (demultiplex.py:216-259): best score, how many carry it, the first of them
+    int best = 0, nbest = 0, only_pair = 0, only_o = 0;
+    for (int pair = 0; pair < P->NPAIR; pair++)
+        for (int o = 0; o < 2; o++) {
+            if ((o == 0 && ori == 2) || (o == 1 && ori == 1)) continue;
+            CandView v = cand_view(c, pair, o);
+            int sc = cand_score(v);
+            if (sc > best) { best = sc; nbest = 1; only_pair = pair; only_o = o; }
+            else if (sc == best) nbest++;
+        }
+    if (best == 0) {   // no candidate at all (demultiplex.py:202-210)
+        emit_op(E, nullptr, 0, -1, SMX_R_UNKNOWN, -1, -1, 0);
+        return true;
+    }
+    if (best <= 2 && nbest > 1) {
+        // several primer-only candidates (typically both orientations of one pair): no barcode logic involved.
+        // dereplicate=best -> dereplicate_unknown_matches: stable minimum of (-primer_count, primer_dist, file index);
+        // dereplicate=none -> every best candidate is written as UNKNOWN (demultiplex.py:181-197, :480-538)
+        int wkey = 0x7FFFFFFF, wpair = 0, wo = 0;
+        for (int pair = 0; pair < P->NPAIR; pair++)
+            for (int o = 0; o < 2; o++) {
+                if ((o == 0 && ori == 2) || (o == 1 && ori == 1)) continue;
+                CandView v = cand_view(c, pair, o);
+                if (cand_score(v) != best) continue;
+                if (P->derep == SMX_DEREP_NONE) {
+                    emit_op(E, &v, pair * 2 + o, -1, SMX_R_UNKNOWN, c.LP.pair_pool[pair], -1, 0);
+                } else {
+                    int k = key_unknown(c.LP, v);
+                    if (k < wkey) { wkey = k; wpair = pair; wo = o; }
+                }
+            }
+        if (P->derep != SMX_DEREP_NONE) {
+            CandView w = cand_view(c, wpair, wo);
+            emit_op(E, &w, wpair * 2 + wo, -1, SMX_R_UNKNOWN, c.LP.pair_pool[wpair], -1, 0);
+        }
+        return true;
+    }
+    if (nbest != 1) return false;
+    CandView v = cand_view(c, only_pair, only_o);
+    int cand_id = only_pair * 2 + only_o, cand_pool = c.LP.pair_pool[only_pair];
+    bool t1 = !v.b1 || c.hits[v.h1].ntied == 1, t2 = !v.b2 || c.hits[v.h2].ntied == 1;
+    if (best <= 2) {   // dereplicate_unknown_matches / resolve_specimen: UNKNOWN either way
+        emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, cand_pool, -1, 0);
+        return true;
+    }
+    if (best <= 4 && t1 && t2) {   // one (direction, barcode) group
+        emit_partial_or_unknown(E, v, cand_id, cand_pool);
+        return true;
+    }
+    if (best == 5 && t1 && t2 && P->derep == SMX_DEREP_BEST) {
+        int spec = specimen_exact(P, global_bc(c, v.h1, c.hits[v.h1].first_tied),
+                                  global_bc(c, v.h2, c.hits[v.h2].first_tied), v.f, v.r);
+        if (spec >= 0) emit_op(E, &v, cand_id, spec, SMX_R_DEREP_FULL, P->spec_pool[spec], -1, 0);
+        else emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, cand_pool, -1, SMX_OPF_NO_SPECIMEN);
+        return true;
+    }
+    return false;
+}
+
+// General scorer (deferred kernel only): the reference's selection / dereplication in full.
+__device__ inline void score_general(Emitter &E, int ori) {
+    const ReadCtx &c = *E.c;
+    const DevPanel *P = c.P;
     int best = 0;
     for (int pair = 0; pair < P->NPAIR; pair++)
         for (int o = 0; o < 2; o++) {
@@ -510,40 +591,9 @@ __device__ inline void score_read(Emitter &E, int ori) {
             int sc = cand_score(v);
             best = sc > best ? sc : best;
         }
-    if (best == 0) {   // no candidate at all (demultiplex.py:202-210)
+    if (best == 0) {
         emit_op(E, nullptr, 0, -1, SMX_R_UNKNOWN, -1, -1, 0);
         return;
-    }
-    // ---- fast path: exactly one candidate carries the best score and no barcode tie is involved.  Every
-    // dereplication group then has one member, so the general machinery below reduces to a single emission.
-    {
-        int nbest = 0, only_pair = 0, only_o = 0;
-        for (int pair = 0; pair < P->NPAIR; pair++)
-            for (int o = 0; o < 2; o++) {
-                if ((o == 0 && ori == 2) || (o == 1 && ori == 1)) continue;
-                CandView v = cand_view(c, pair, o);
-                if (cand_score(v) == best) { if (nbest == 0) { only_pair = pair; only_o = o; } nbest++; }
-            }
-        if (nbest == 1) {
-            CandView v = cand_view(c, only_pair, only_o);
-            int cand_id = only_pair * 2 + only_o, cand_pool = c.LP.pair_pool[only_pair];
-            bool t1 = !v.b1 || c.hits[v.h1].ntied == 1, t2 = !v.b2 || c.hits[v.h2].ntied == 1;
-            if (best <= 2) {   // dereplicate_unknown_matches / resolve_specimen: UNKNOWN either way
-                emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, cand_pool, -1, 0);
-                return;
-            }
-            if (best <= 4 && t1 && t2) {   // one (direction, barcode) group
-                emit_partial_or_unknown(E, v, cand_id, cand_pool);
-                return;
-            }
-            if (best == 5 && t1 && t2 && P->derep == SMX_DEREP_BEST) {
-                int spec = specimen_exact(P, global_bc(c, v.h1, c.hits[v.h1].first_tied),
-                                          global_bc(c, v.h2, c.hits[v.h2].first_tied), v.f, v.r);
-                if (spec >= 0) emit_op(E, &v, cand_id, spec, SMX_R_DEREP_FULL, P->spec_pool[spec], -1, 0);
-                else emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, cand_pool, -1, SMX_OPF_NO_SPECIMEN);
-                return;
-            }
-        }
     }
     if (P->derep == SMX_DEREP_NONE) {   // demultiplex.py:181-197
         FOR_BEST_CANDS(c, ori, best, {
@@ -661,7 +711,8 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
                                                     unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist,
-                                                    unsigned *tile_counter, int use_slots) {
+                                                    unsigned *tile_counter, int use_slots, unsigned char *defer_recs,
+                                                    unsigned *n_deferred) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
     const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
@@ -730,10 +781,12 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
     const int stride = P->wstride;
     const int kidx = P->kidx, pfmin = P->pfmin;
     const uint32_t n_tiles = (n_reads + R - 1) / R;
-    // diagnostic phase timing (SMX_PHASE_TIMING=1): thread 0 accumulates s_memtime deltas per phase
-    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    // diagnostic phase timing (SMX_PHASE_TIMING=1): thread 0 accumulates s_memtime deltas per phase, in LDS so that
+    // the accumulators cost no registers in the production path
+    unsigned long long *tacc = (unsigned long long *)(lds + T.tacc);   // [0..9] sums, [10] previous stamp
     const bool timing = P->dbg_phase != nullptr && tid == 0;
-#define STAMP(i) do { if (timing) { unsigned long long _t = clock64(); tacc[i] += _t - tprev; tprev = _t; } } while (0)
+    if (timing) for (int i = 0; i < 11; i++) tacc[i] = 0;
+#define STAMP(i) do { if (timing) { unsigned long long _t = clock64(); tacc[i] += _t - tacc[10]; tacc[10] = _t; } } while (0)
     // dynamic tile queue: workgroups pull tiles from a global counter (zeroed on the stream before the
     // launch), so the tail is one tile long whatever the residency turns out to be
     for (;;) {
@@ -744,7 +797,7 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
         const uint32_t r0 = tile * R;
         const int nr = (int)((n_reads - r0) < (uint32_t)R ? (n_reads - r0) : (uint32_t)R);
         const int nh = nr * H;
-        if (timing) tprev = clock64();
+        if (timing) tacc[10] = clock64();
 
         // ---- phase 1: windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
         if (tid < nr) { lensL[tid] = lens[r0 + tid]; ocnt[2 * tid] = 0; ocnt[2 * tid + 1] = 0; }
@@ -992,12 +1045,21 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                     const EntL en = ents[ei];
                     if (!en.ok) continue;
                     const int hh = en.hit, h = hh % H, p = h >> 1, X = h & 1, r = hh / H;
-                    unsigned seen[8];
-                    bitsliced_shw(bsre + p * T.BSP + w, MBW, codes + (r * 2 + X) * CS + en.tj0, en.ncol, bsm, kidx, seen);
+                    const unsigned char *cwt = codes + (r * 2 + X) * CS + en.tj0;
                     unsigned *dm = dmask + ((en.slot >> logG) * (kidx + 1)) * MBW + w;
+                    if (kidx < 4) {
+                        unsigned seen[4];
+                        bitsliced_shw<4>(bsre + p * T.BSP + w, MBW, cwt, en.ncol, bsm, kidx, seen);
 #pragma unroll
-                    for (int d = 0; d < 8; d++)
-                        if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
+                        for (int d = 0; d < 4; d++)
+                            if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
+                    } else {
+                        unsigned seen[8];
+                        bitsliced_shw<8>(bsre + p * T.BSP + w, MBW, cwt, en.ncol, bsm, kidx, seen);
+#pragma unroll
+                        for (int d = 0; d < 8; d++)
+                            if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
+                    }
                 }
             } else
             // 3b: barcode scan, one lane per (entry, barcode slot)
@@ -1166,11 +1228,33 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                     E.c = &c; E.primary = opsL + r; E.extra = extra; E.extra_cap = extra_cap; E.n_extra = n_extra;
                     E.counts = counts; E.emitlog = emitlog + r * SMX_MAX_EMIT; E.aggr = aggr; E.read = r0 + r;
                     E.n = 0; E.matched = false; E.overflow = false;
-                    score_read(E, ori);
-                    opsL[r].n_ops = (uint16_t)E.n;
-                    if (E.matched) atomicAdd(&aggr[1], 1);
-                    if (E.n > 1) atomicAdd(&aggr[6], 1);
-                    if (E.overflow) atomicAdd(&aggr[7], 1);
+                    if (score_fast(E, ori)) {
+                        opsL[r].n_ops = (uint16_t)E.n;
+                        if (E.matched) atomicAdd(&aggr[1], 1);
+                        if (E.n > 1) atomicAdd(&aggr[6], 1);
+                        if (E.overflow) atomicAdd(&aggr[7], 1);
+                    } else if (!SMX_DEFER) {
+                        score_general(E, ori);
+                        opsL[r].n_ops = (uint16_t)E.n;
+                        if (E.matched) atomicAdd(&aggr[1], 1);
+                        if (E.n > 1) atomicAdd(&aggr[6], 1);
+                        if (E.overflow) atomicAdd(&aggr[7], 1);
+                    } else {
+                        // rare: ties or several best candidates -> dump this read's hit table for the general scorer
+                        unsigned slot = atomicAdd(n_deferred, 1u);
+                        unsigned char *rec = defer_recs + (size_t)slot * deferred_rec_bytes(H, MBW);
+                        int *hdr = (int *)rec;
+                        hdr[0] = (int)(r0 + r); hdr[1] = L; hdr[2] = ori; hdr[3] = 0;
+                        HitL *dh = (HitL *)(rec + 16);
+                        for (int h = 0; h < H; h++) dh[h] = hits[r * H + h];
+                        unsigned *dt = (unsigned *)(rec + 16 + H * sizeof(HitL));
+                        for (int w = 0; w < H * MBW; w++) dt[w] = tiem[r * H * MBW + w];
+                        smx_op op;   // placeholder: the deferred kernel overwrites ops[read]
+                        op.sample = -1; op.trim_start = 0; op.trim_end = 0; op.pool = -1; op.p1 = op.p2 = -1; op.barcode = -1;
+                        op.dist[0] = op.dist[1] = op.dist[2] = op.dist[3] = -1;
+                        op.rtype = SMX_R_UNKNOWN; op.flags = 0; op.n_ops = 0; op.read = r0 + r;
+                        opsL[r] = op;
+                    }
                 }
             }
         }
@@ -1207,6 +1291,44 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
 #undef STAMP
     // block aggregates -> global counters
     if (tid < 8 && aggr[tid]) atomicAdd(&counts[tid], (unsigned long long)aggr[tid]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deferred reads.  Record layout in global memory (fixed size per panel, 16-byte aligned):
+//   int read, L, ori, pad;  HitL hits[H];  unsigned tiem[H * MBW]
+__global__ __launch_bounds__(64) void score_deferred_kernel(DevPanel Pv, const unsigned char *recs,
+                                                            const unsigned *n_deferred, smx_op *ops, smx_op *extra,
+                                                            uint32_t extra_cap, uint32_t *n_extra,
+                                                            unsigned long long *counts) {
+    __shared__ int aggr[12];
+    const DevPanel *P = &Pv;
+    const int H = 2 * P->NP, MBW = (P->maxB + 31) / 32, rb = deferred_rec_bytes(H, MBW);
+    if (threadIdx.x < 12) aggr[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned nd = *n_deferred;
+    for (unsigned i = blockIdx.x * 64 + threadIdx.x; i < nd; i += gridDim.x * 64) {
+        const unsigned char *rec = recs + (size_t)i * rb;
+        const int *hdr = (const int *)rec;
+        unsigned emitlog[SMX_MAX_EMIT];
+        ReadCtx c;
+        c.P = P;
+        c.LP.pm = P->pm; c.LP.pk = P->pk; c.LP.pdir = P->pdir; c.LP.pfidx = P->pfidx; c.LP.pbc_off = P->pbc_off;
+        c.LP.pbc = P->pbc; c.LP.bm = P->bm; c.LP.pair_f = P->pair_f; c.LP.pair_r = P->pair_r; c.LP.pair_pool = P->pair_pool;
+        c.hits = (const HitL *)(rec + 16);
+        c.tiem = (const unsigned *)(rec + 16 + H * sizeof(HitL));
+        c.MBW = MBW; c.L = hdr[1]; c.S = P->S; c.g = end_geom(hdr[1], P->S);
+        Emitter E;
+        E.c = &c; E.primary = ops + hdr[0]; E.extra = extra; E.extra_cap = extra_cap; E.n_extra = n_extra;
+        E.counts = counts; E.emitlog = emitlog; E.aggr = aggr; E.read = (unsigned)hdr[0];
+        E.n = 0; E.matched = false; E.overflow = false;
+        score_general(E, hdr[2]);
+        ops[hdr[0]].n_ops = (uint16_t)E.n;
+        if (E.matched) atomicAdd(&aggr[1], 1);
+        if (E.n > 1) atomicAdd(&aggr[6], 1);
+        if (E.overflow) atomicAdd(&aggr[7], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && aggr[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)aggr[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1248,18 +1370,26 @@ __global__ void align_kernel(const unsigned long long *peq, const unsigned long 
 extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t lds_bytes, void *stream,
                                 const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops,
                                 smx_op *d_extra, uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts,
-                                smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter, int use_slots) {
+                                smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter, int use_slots,
+                                unsigned char *d_defer) {
     hipStream_t s = (hipStream_t)stream;
-    hipError_t me = hipMemsetAsync(d_tile_counter, 0, sizeof(unsigned), s);
+    // d_tile_counter[0] = tile queue head, [1] = number of deferred reads
+    hipError_t me = hipMemsetAsync(d_tile_counter, 0, 2 * sizeof(unsigned), s);
     if (me != hipSuccess) return (int)me;
     if (use64)
         hipLaunchKernelGGL(smx::demux_kernel<unsigned long long>, dim3(grid), dim3(256), lds_bytes, s, *P, d_windows,
                            d_lens, n_reads, R, d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts,
-                           d_hits, d_bdist, d_tile_counter, use_slots);
+                           d_hits, d_bdist, d_tile_counter, use_slots, d_defer, d_tile_counter + 1);
     else
         hipLaunchKernelGGL(smx::demux_kernel<unsigned>, dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens,
                            n_reads, R, d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits,
-                           d_bdist, d_tile_counter, use_slots);
+                           d_bdist, d_tile_counter, use_slots, d_defer, d_tile_counter + 1);
+    me = hipGetLastError();
+    if (me != hipSuccess) return (int)me;
+    // general scorer over the deferred reads (usually well under 1 %): ordered after the main kernel on the stream
+    if (SMX_DEFER)
+    hipLaunchKernelGGL(smx::score_deferred_kernel, dim3(512), dim3(64), 0, s, *P, d_defer, d_tile_counter + 1, d_ops, d_extra,
+                       extra_cap, d_n_extra, (unsigned long long *)d_counts);
     return (int)hipGetLastError();
 }
 
@@ -1275,6 +1405,10 @@ extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
                          : hipFuncSetAttribute((const void *)smx::demux_kernel<unsigned>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     return (int)e;
+}
+
+extern "C" size_t smx_deferred_rec_bytes(int NP, int maxB) {   // 0: the build keeps the general scorer inline
+    return SMX_DEFER ? (size_t)smx::deferred_rec_bytes(2 * NP, (maxB + 31) / 32) : 0;
 }
 
 extern "C" int smx_query_occupancy(int use64, size_t lds_bytes, int *blocks_per_cu) {

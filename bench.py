@@ -129,10 +129,16 @@ def main():
     from specimux_amd.demultiplex import compiled_panel
     from specimux_amd.cli import parse_args
 
+    if os.environ.get("SMX_BENCH_SAME_DEVICE"):   # rehearsal on a 1-GPU box only: every rank on GPU 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rehearsal = bool(os.environ.get("SMX_BENCH_SAME_DEVICE"))   # gloo + shared GPU 0: RCCL refuses two ranks per device
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     lib = _lib.load()
     args = parse_args(["specimux", pf, sf, "reads.fastq"])   # the reference's default flags
     reg = sa.read_primers_file(pf)
@@ -154,7 +160,8 @@ def main():
     stream = torch.cuda.current_stream()
 
     from specimux_amd.distributed import CountsReducer
-    reducer = CountsReducer(world, rank, "rccl")   # RCCL communicator of the C ABI (id over torch.distributed)
+    # RCCL communicator of the C ABI (its 128-byte id travels over torch.distributed)
+    reducer = CountsReducer(world, rank, "torch" if rehearsal else "rccl")
 
     def step():
         d_nextra.zero_()
@@ -183,7 +190,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

@@ -37,16 +37,23 @@ class CountsReducer:
         self.world, self.rank, self.backend = world, rank, backend
         self.comm = C.c_void_p()
         if world > 1 and backend == "rccl":
+            import sys
             import torch.distributed as dist
             from . import _lib
             lib = _lib.load()
-            uid = (C.c_uint8 * 128)()
-            if rank == 0:
-                _lib.check(lib.smx_comm_unique_id(uid))
-            box = [bytes(uid)]
-            dist.broadcast_object_list(box, src=0)
-            uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
-            _lib.check(lib.smx_comm_init(uid, world, rank, C.byref(self.comm)))
+            try:
+                uid = (C.c_uint8 * 128)()
+                if rank == 0:
+                    _lib.check(lib.smx_comm_unique_id(uid))
+                box = [bytes(uid)]
+                dist.broadcast_object_list(box, src=0)
+                uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+                _lib.check(lib.smx_comm_init(uid, world, rank, C.byref(self.comm)))
+            except Exception as e:   # same collective through torch.distributed's RCCL communicator instead
+                print(f"[specimux_amd] C-ABI RCCL communicator unavailable ({e}); using torch.distributed all_reduce",
+                      file=sys.stderr)
+                self.comm = C.c_void_p()
+                self.backend = "torch"
 
     def allreduce_(self, counts, stream_ptr=None):
         """In-place sum of an int64/uint64 tensor over all ranks."""
@@ -58,6 +65,9 @@ class CountsReducer:
                                                         C.c_void_p(stream_ptr) if stream_ptr else None))
         else:
             import torch.distributed as dist
+            if stream_ptr:   # counts were produced on a side stream: make the collective's stream see them
+                import torch
+                torch.cuda.current_stream().synchronize()
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         return counts
 

@@ -241,6 +241,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
                             bsre[(((size_t)p * 16 + row) * 16 + c) * MBWh + (bi >> 5)] |= 1u << (bi & 31);
             }
     h.bs_ok = bs_ok ? 1 : 0;
+    if (const char *e = getenv("SMX_TEST_CAPS")) sscanf(e, "%d,%d", &h.cap_hits, &h.cap_ents);
     h.bs_m = bm[0];
     if (h.pfmin != 0 && h.pfmin < 2) { delete P; return fail(SMX_ERR_UNSUPPORTED, "prefilter min length %d < 2: disable the prefilter", h.pfmin); }
     if (h.bmax + h.kidx > 200) { delete P; return fail(SMX_ERR_UNSUPPORTED, "barcode length + k too large"); }

@@ -38,6 +38,7 @@ struct DevPanel {
     // bit-sliced barcode scan (lean mode): all barcodes one length bs_m <= 16, k <= 7.
     // bs_re[((p * 16 + row) * 16 + code) * MBW + w] = bitmask over primer p's barcode list: barcode_rc[row] eq code
     int bs_ok, bs_m;
+    int cap_hits, cap_ents;   // test hook (SMX_TEST_CAPS=h,e): force small barcode rounds; 0 = default sizing
     const unsigned *bs_re;
     unsigned long long *dbg_phase;        // SMX_PHASE_TIMING=1: [grid][16] cycle sums per phase (diagnostic build-in)
 };

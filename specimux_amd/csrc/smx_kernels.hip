@@ -132,7 +132,8 @@ static_assert(sizeof(EntL) == 8, "EntL layout");
 
 template <typename PW>
 __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, int maxB, int need_starts,
-                                                    int npmeta, int kidx, int slots, int bs) {
+                                                    int npmeta, int kidx, int slots, int bs, int cap_hits = 0,
+                                                    int cap_ents = 0) {
     TileLayout t;
     int H = 2 * NP, MW = (S + 31) / 32;
     t.CS = 4 * (((S + 3) / 4) | 1);
@@ -148,6 +149,8 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     int fit = slots ? (16 * 1024) / (t.G * 4) : (4 * 1024) / ((kidx + 1) * t.MBW * 4);
     t.CAPH = dense < fit ? dense : (fit < 1 ? 1 : fit);
     t.CAPE = t.CAPH + t.CAPH / 4 < 320 ? 320 : t.CAPH + t.CAPH / 4;   // >= 256 = max locations of one hit (progress)
+    if (cap_hits > 0 && cap_hits < t.CAPH) t.CAPH = cap_hits;          // test hook: many small rounds
+    if (cap_ents >= S && cap_ents < t.CAPE) t.CAPE = cap_ents;         // (a hit has at most S locations)
     int o = 0;
     t.tacc = o;  o += 11 * 8 + 8;
     t.ppeq = o;  o += t.NPs * 16 * (int)sizeof(PW);
@@ -719,7 +722,8 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
     const int n_pbc = P->n_pbc, NPAIR = P->NPAIR;
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
     const int use_bs = (P->bs_ok && !use_slots) ? 1 : 0;
-    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta, P->kidx, use_slots, P->bs_ok);
+    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta, P->kidx, use_slots, P->bs_ok,
+                                         P->cap_hits, P->cap_ents);
     PW *ppeq = (PW *)(lds + T.ppeq);        // [code][primer], stride NPs
     PW *prpeq = (PW *)(lds + T.prpeq);
     unsigned *bpeq = (unsigned *)(lds + T.bpeq);   // [code][barcode], stride NBs

@@ -376,3 +376,53 @@ def test_cli_end_to_end_synthetic(lib, c2, tmp_path, variant):
     assert got == exp
     log = (out / "log.txt").read_text()
     assert f"Processed {total:,} sequences, match rate: {matched / total:.1%}" in log
+
+
+# ------------------------------------------------------------------ panel shapes that select other kernel paths
+def _custom_panel(tmp_path_factory, name, n_fwd, n_rev, bc_len, min_dist, fwd_primer=None, mixed=False, seed=7):
+    from specimux_amd import synth
+    f, r = synth.make_barcodes(n_fwd, n_rev, length=bc_len, min_dist=min_dist, seed=seed)
+    pools = [("ITS", "FWD", fwd_primer or synth.ITS1F, "ITS4", synth.ITS4)]
+    pan = synth.Panel(pools, f, r)          # the reads are generated from the uniform panel
+    files = pan
+    if mixed:   # the panel FILE gets one shorter forward barcode: mixed lengths (the prefilter must then be off)
+        files = synth.Panel(pools, [f[0][:-2]] + f[1:], r)
+    return pan, tmp_panel(tmp_path_factory, files, name)
+
+
+@pytest.mark.parametrize("shape", ["96x4_multiword", "24nt_barcodes", "40nt_primer_64bit", "mixed_lengths"])
+def test_panel_shapes(lib, tmp_path_factory, shape):
+    from specimux_amd import synth
+    flags = {}
+    if shape == "96x4_multiword":      # > 64 barcodes on one primer: 3-word tie masks, G = 128 slots
+        pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 96, 4, 13, 5)
+    elif shape == "24nt_barcodes":     # longer than the bit-sliced path's 16 rows: per-barcode lean path, larger k
+        pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 12, 8, 24, 10)
+        flags = dict(disable_prefilter=True)
+    elif shape == "40nt_primer_64bit":  # primer longer than 32 nt: 64-bit primer words
+        pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 8, 6, 13, 6,
+                                      fwd_primer="CTTGGTCATTTAGAGGAAGTAAAAGTCGTAACAAGGTTTCC")
+    else:
+        pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 8, 6, 13, 6, mixed=True)
+        flags = dict(disable_prefilter=True)
+    rs = synth.make_reads(pan, 500, 99, windows_only=False)
+    reads = reads_from_set(rs, range(500), 80)
+    for fl in (flags, dict(flags, trim="tails")):
+        both = Both(pf, sf, **fl)
+        both.assert_hits_equal(reads[:80], f"{shape} {fl}")
+        got = both.assert_ops_equal(reads, f"{shape} {fl}")
+        assert sum(1 for k in got if k[6] == "DEREP") > 100
+
+
+def test_forced_small_barcode_rounds(c2, monkeypatch):
+    """SMX_TEST_CAPS shrinks the per-round capacities (hits, entries) so that every tile needs many barcode
+    rounds: the multi-round bookkeeping must give the same records as one round."""
+    from specimux_amd import synth
+    pan, (pf, sf) = c2
+    rs = synth.make_reads(pan, 700, 31, windows_only=False)
+    reads = reads_from_set(rs, range(700), 80) + [r for r in _edge_reads(pan) if r[0] != "u_base"]
+    monkeypatch.setenv("SMX_TEST_CAPS", "5,80")
+    for fl in (dict(), dict(trim="tails"), dict(disable_preorient=True)):
+        both = Both(pf, sf, **fl)
+        both.assert_hits_equal(reads[:100], f"caps {fl}")
+        both.assert_ops_equal(reads, f"caps {fl}")

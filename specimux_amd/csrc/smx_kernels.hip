@@ -155,7 +155,7 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.tacc = o;  o += 11 * 8 + 8;
     t.ppeq = o;  o += t.NPs * 16 * (int)sizeof(PW);
     t.prpeq = o; o += (need_starts ? t.NPs * 16 * (int)sizeof(PW) : 0);
-    t.bpeq = o;  o += t.NBs * 16 * 4;
+    t.bpeq = o;  o += (bs && !slots) ? 0 : t.NBs * 16 * 4;
     t.BSP = (16 * 16 + 4) * t.MBW;              // words per primer in the bit-sliced table (+4: bank skew)
     t.bsre = o;  o += (bs && !slots) ? NP * t.BSP * 4 : 0;
     t.lut = o;   o += 512;
@@ -754,7 +754,8 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
         ppeq[c * NPs + p] = (PW)P->ppeq[i];
         if (P->need_starts) prpeq[c * NPs + p] = (PW)P->prpeq[i];
     }
-    for (int i = tid; i < NB * 16; i += 256) bpeq[(i & 15) * NBs + (i >> 4)] = P->bpeq[i];
+    if (!use_bs)
+        for (int i = tid; i < NB * 16; i += 256) bpeq[(i & 15) * NBs + (i >> 4)] = P->bpeq[i];
     if (use_bs)
         for (int i = tid; i < NP * 16 * 16 * T.MBW; i += 256) {
             int p = i / (256 * T.MBW);

@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from .native_io import Reader, Writer
 
-BATCH_READS = 262144          # reads per kernel launch
+BATCH_READS = 131072          # reads per kernel launch
 BATCH_BYTES = 512 << 20       # ... or this many bytes of parsed records, whichever comes first
 
 

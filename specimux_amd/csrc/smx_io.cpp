@@ -1,5 +1,6 @@
 // smx_io.cpp -- host streaming helpers of libsmx.so: FASTQ/FASTA reader, window packer, output writer.
-// The steps on either side of the GPU hot path; plain C++17 + zlib, no device work.
+// The steps on either side of the GPU hot path; plain C++17 + zlib + std::thread,
+// no device work.
 //
 // Reference behaviour restated (paths relative to the reference repo):
 //   reader : Bio.SeqIO "fastq"/"fasta" as used by open_sequence_file (src/specimux/io_utils.py:429-450) --
@@ -8,16 +9,28 @@
 //            already as long as the sequence; id = first whitespace-delimited word of the title.
 //   writer : create_write_operation's orientation + slicing (demultiplex.py:74-78) and
 //            OutputManager.write_sequence / _make_filename (io_utils.py:197-268).
+//
+// Two reader engines:
+//   * general (serial): any legal FASTQ / FASTA, plain or gzip, through zlib; records are copied into the batch.
+//   * fast (parallel, zero-copy): uncompressed FASTQ with strict 4-line records.  A block of the file is read
+//     once, split at record boundaries ('@' line whose line+2 starts with '+') among worker threads, and every
+//     worker only builds record descriptors that point into the block.  The first irregular record (wrapped
+//     lines, blank lines) switches the reader permanently to the general engine at that block's offset.
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -29,55 +42,92 @@ namespace {
 
 inline bool is_space(unsigned char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
 
+int io_threads() {
+    static int n = [] {
+        int v = 0;
+        if (const char *e = getenv("SMX_IO_THREADS")) v = atoi(e);
+        if (v <= 0) {
+            v = (int)std::thread::hardware_concurrency();
+            // respect a cgroup CPU quota if there is one
+            if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+                char q[32];
+                long period = 0;
+                if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+                    long cpus = atol(q) / period;
+                    if (cpus >= 1 && cpus < v) v = (int)cpus;
+                }
+                fclose(f);
+            }
+            v = std::min(v, 8);
+        }
+        return std::max(v, 1);
+    }();
+    return n;
+}
+
 struct Rec {
-    uint64_t id_off, seq_off, qual_off;   // into smx_batch::data; qual_off == UINT64_MAX for FASTA
+    uint64_t id_off, seq_off, qual_off;   // into the segment's base; qual_off == UINT64_MAX for FASTA
     uint32_t id_len, seq_len;
+    uint64_t src_off;                     // fast engine: offset of the record's '@' inside the block
+};
+
+struct Segment {
+    const char *base = nullptr;           // own.data() (general engine) or a pointer into the shared block
+    std::vector<char> own;
+    std::vector<Rec> recs;
 };
 
 }  // namespace
 
 struct smx_batch {
-    std::vector<char> data;   // ids, sequences, qualities, each contiguous
-    std::vector<Rec> recs;
+    std::vector<Segment> segs;
+    std::vector<uint32_t> first;          // first[i] = global index of segs[i].recs[0]; first.back() = total
+    std::shared_ptr<std::vector<char>> block;   // fast engine: the file block the segments point into
+    uint32_t n = 0;
+
+    void clear() { segs.clear(); first.clear(); block.reset(); n = 0; }
+    void finish() {
+        first.assign(segs.size() + 1, 0);
+        for (size_t i = 0; i < segs.size(); i++) first[i + 1] = first[i] + (uint32_t)segs[i].recs.size();
+        n = first.back();
+    }
+    inline void locate(uint32_t i, const Segment **s, const Rec **r) const {
+        size_t k = (size_t)(std::upper_bound(first.begin(), first.end(), i) - first.begin()) - 1;
+        *s = &segs[k];
+        *r = &segs[k].recs[i - first[k]];
+    }
 };
 
 struct smx_reader {
-    gzFile gz = nullptr;      // zlib reads plain files transparently as well
+    std::string path;
     bool fastq = true;
+    // ---- general engine
+    gzFile gz = nullptr;
     std::vector<char> buf;    // unconsumed bytes [pos, end)
     size_t pos = 0, end = 0;
     bool eof = false;
     uint64_t line_no = 0;
+    // ---- fast engine (plain FASTQ)
+    int fd = -1;
+    uint64_t fsize = 0, fpos = 0;
+    bool fast = false;
 
-    // Returns the next line WITHOUT its terminator ('\n' or '\r\n'); false at end of file.  The pointer
-    // stays valid until the next call.
     bool next_line(const char **p, size_t *n) {
         for (;;) {
             const char *s = buf.data() + pos;
             const char *nl = (const char *)memchr(s, '\n', end - pos);
-            if (nl) {
-                *p = s;
-                *n = (size_t)(nl - s);
-                pos += *n + 1;
-                line_no++;
-                return true;
-            }
+            if (nl) { *p = s; *n = (size_t)(nl - s); pos += *n + 1; line_no++; return true; }
             if (eof) {
                 if (pos == end) return false;
-                *p = s;
-                *n = end - pos;
-                pos = end;
-                line_no++;
+                *p = s; *n = end - pos; pos = end; line_no++;
                 return true;
             }
-            // refill: move the partial line to the front, grow if it fills the buffer
             if (pos > 0) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
             if (end == buf.size()) buf.resize(buf.size() * 2);
             int got = gzread(gz, buf.data() + end, (unsigned)std::min<size_t>(buf.size() - end, 1u << 30));
             if (got <= 0) eof = true; else end += (size_t)got;
         }
     }
-    // peek at the first byte of the next line (0 at EOF) without consuming it
     int peek() {
         for (;;) {
             if (pos < end) return (unsigned char)buf[pos];
@@ -89,46 +139,251 @@ struct smx_reader {
     }
 };
 
-struct smx_writer {
-    std::string out_dir, prefix;
-    bool fastq = true;
-    std::vector<std::string> specimens, pools, primers, barcodes;
-    struct File { std::string path; std::string pending; bool dir_made = false; };
-    std::vector<File> files;
-    std::unordered_map<std::string, size_t> index;   // relative path -> files[]
-    int first_errno = 0;
-    std::string scratch;
-    unsigned char comp[256];
-
-    size_t file_for(const std::string &rel) {
-        auto it = index.find(rel);
-        if (it != index.end()) return it->second;
-        files.push_back(File{out_dir + "/" + rel, std::string(), false});
-        index.emplace(rel, files.size() - 1);
-        return files.size() - 1;
-    }
-    static void mkdirs(const std::string &path) {   // parents of `path`
-        for (size_t i = 1; i < path.size(); i++)
-            if (path[i] == '/') { std::string d = path.substr(0, i); mkdir(d.c_str(), 0777); }
-    }
-    void flush(File &f) {
-        if (f.pending.empty()) return;
-        if (!f.dir_made) { mkdirs(f.path); f.dir_made = true; }
-        int fd = open(f.path.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0666);
-        if (fd < 0) { if (!first_errno) first_errno = errno; f.pending.clear(); return; }
-        const char *p = f.pending.data();
-        size_t left = f.pending.size();
-        while (left) {
-            ssize_t w = write(fd, p, left);
-            if (w < 0) { if (errno == EINTR) continue; if (!first_errno) first_errno = errno; break; }
-            p += w; left -= (size_t)w;
-        }
-        close(fd);
-        f.pending.clear();
-    }
-};
-
 namespace {
+
+void append_trimmed(std::vector<char> &dst, const char *p, size_t n, bool drop_inner_spaces) {
+    while (n && is_space((unsigned char)p[n - 1])) n--;
+    size_t a = 0;
+    while (a < n && is_space((unsigned char)p[a])) a++;
+    if (!drop_inner_spaces) { dst.insert(dst.end(), p + a, p + n); return; }
+    for (size_t i = a; i < n; i++) if (p[i] != ' ') dst.push_back(p[i]);
+}
+
+// ---------------------------------------------------------------- general engine (serial, copies records)
+int next_general(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batch *b) {
+    b->segs.emplace_back();
+    Segment &sg = b->segs.back();
+    std::vector<char> &data = sg.own;
+    const char *p;
+    size_t n;
+    while (sg.recs.size() < max_reads && (max_bytes == 0 || data.size() < max_bytes)) {
+        Rec rec;
+        rec.src_off = 0;
+        if (r->fastq) {
+            bool have = false;
+            while ((have = r->next_line(&p, &n))) {   // skip blank lines between records
+                size_t k = n;
+                while (k && is_space((unsigned char)p[k - 1])) k--;
+                if (k) break;
+            }
+            if (!have) break;
+            if (p[0] != '@') return smx_set_error(SMX_ERR_ARG, "line %llu: Records in Fastq files should start with '@' character", (unsigned long long)r->line_no);
+            size_t a = 1;
+            while (a < n && is_space((unsigned char)p[a])) a++;
+            size_t e = a;
+            while (e < n && !is_space((unsigned char)p[e])) e++;
+            rec.id_off = data.size();
+            rec.id_len = (uint32_t)(e - a);
+            data.insert(data.end(), p + a, p + e);
+            rec.seq_off = data.size();
+            bool plus = false;
+            while (r->next_line(&p, &n)) {
+                if (n && p[0] == '+') { plus = true; break; }
+                append_trimmed(data, p, n, false);
+            }
+            if (!plus) return smx_set_error(SMX_ERR_ARG, "line %llu: End of file without quality information.", (unsigned long long)r->line_no);
+            uint64_t slen = data.size() - rec.seq_off;
+            if (slen > 0x7FFFFFFFull) return smx_set_error(SMX_ERR_UNSUPPORTED, "read longer than 2^31-1 bases");
+            rec.seq_len = (uint32_t)slen;
+            rec.qual_off = data.size();
+            if (r->next_line(&p, &n)) append_trimmed(data, p, n, false);
+            for (;;) {
+                int c = r->peek();
+                if (c < 0) break;
+                uint64_t qlen = data.size() - rec.qual_off;
+                if (c == '@' && qlen >= slen) break;
+                if (!r->next_line(&p, &n)) break;
+                append_trimmed(data, p, n, false);
+            }
+            if (data.size() - rec.qual_off != slen)
+                return smx_set_error(SMX_ERR_ARG, "line %llu: Lengths of sequence and quality values differs (%llu and %llu).",
+                                     (unsigned long long)r->line_no, (unsigned long long)slen,
+                                     (unsigned long long)(data.size() - rec.qual_off));
+        } else {
+            bool have = false;
+            while ((have = r->next_line(&p, &n))) if (n && p[0] == '>') break;
+            if (!have) break;
+            size_t a = 1;
+            while (a < n && is_space((unsigned char)p[a])) a++;
+            size_t e = a;
+            while (e < n && !is_space((unsigned char)p[e])) e++;
+            rec.id_off = data.size();
+            rec.id_len = (uint32_t)(e - a);
+            data.insert(data.end(), p + a, p + e);
+            rec.seq_off = data.size();
+            for (;;) {
+                int c = r->peek();
+                if (c < 0 || c == '>') break;
+                if (!r->next_line(&p, &n)) break;
+                append_trimmed(data, p, n, true);
+            }
+            uint64_t slen = data.size() - rec.seq_off;
+            if (slen > 0x7FFFFFFFull) return smx_set_error(SMX_ERR_UNSUPPORTED, "read longer than 2^31-1 bases");
+            rec.seq_len = (uint32_t)slen;
+            rec.qual_off = UINT64_MAX;
+        }
+        sg.recs.push_back(rec);
+    }
+    sg.base = data.data();
+    return SMX_OK;
+}
+
+// ---------------------------------------------------------------- fast engine (parallel, zero-copy)
+inline const char *line_end(const char *p, const char *end) {
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+    return nl ? nl : end;
+}
+
+// First position >= from that starts a strict record: a line starting with '@' whose line+2 starts with '+'.
+// `from` must be at a line start.  Returns end if there is none.
+const char *find_record_start(const char *from, const char *end) {
+    const char *p = from;
+    while (p < end) {
+        const char *e1 = line_end(p, end);
+        if (*p == '@' && e1 < end) {
+            const char *l2 = e1 + 1;
+            if (l2 < end) {
+                const char *e2 = line_end(l2, end);
+                if (e2 < end && e2 + 1 < end && e2[1] == '+') return p;
+            }
+        }
+        if (e1 >= end) break;
+        p = e1 + 1;
+    }
+    return end;
+}
+
+// Parse strict 4-line records in [p, stop) (records STARTING before stop), never reading past `end`.
+// Returns false on the first irregular record.  *consumed = where parsing stopped (a record start or end).
+bool parse_strict(const char *base, const char *p, const char *stop, const char *end, bool last_block,
+                  std::vector<Rec> &out, const char **consumed) {
+    while (p < stop) {
+        if (*p != '@') return false;
+        const char *e1 = line_end(p, end);
+        if (e1 >= end) { *consumed = p; return true; }            // incomplete record: leave it for the next block
+        const char *s = e1 + 1, *e2 = line_end(s, end);
+        if (e2 >= end) { *consumed = p; return true; }
+        const char *pl = e2 + 1;
+        if (pl >= end) { *consumed = p; return true; }
+        if (*pl != '+') return false;                              // wrapped sequence or empty read: general engine
+        const char *e3 = line_end(pl, end);
+        if (e3 >= end) { *consumed = p; return true; }
+        const char *q = e3 + 1, *e4 = line_end(q, end);
+        if (e4 >= end && !last_block) { *consumed = p; return true; }   // quality line may be cut by the block end
+        Rec r;
+        r.src_off = (uint64_t)(p - base);
+        const char *a = p + 1;
+        while (a < e1 && is_space((unsigned char)*a)) a++;
+        const char *ie = a;
+        while (ie < e1 && !is_space((unsigned char)*ie)) ie++;
+        r.id_off = (uint64_t)(a - base);
+        r.id_len = (uint32_t)(ie - a);
+        const char *se = e2;
+        while (se > s && is_space((unsigned char)se[-1])) se--;
+        const char *qe = e4;
+        while (qe > q && is_space((unsigned char)qe[-1])) qe--;
+        if (se == s || (size_t)(se - s) != (size_t)(qe - q)) return false;   // empty or wrapped: general engine decides
+        for (const char *c = s; c < se; c++) if (is_space((unsigned char)*c)) return false;
+        if ((uint64_t)(se - s) > 0x7FFFFFFFull) return false;
+        r.seq_off = (uint64_t)(s - base);
+        r.seq_len = (uint32_t)(se - s);
+        r.qual_off = (uint64_t)(q - base);
+        out.push_back(r);
+        p = e4 < end ? e4 + 1 : end;
+    }
+    *consumed = p;
+    return true;
+}
+
+// Returns 1 = batch filled by the fast engine, 0 = irregular input: caller must use the general engine from fpos.
+int next_fast(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batch *b) {
+    if (r->fpos >= r->fsize) return 1;   // end of file: empty batch
+    uint64_t want = max_bytes ? max_bytes : (256ull << 20);
+    // do not read far more than max_reads records' worth (a surplus is cut off and re-read by the next call)
+    want = std::min<uint64_t>(want, (uint64_t)max_reads * 4096 + (1u << 20));
+    for (;;) {
+        uint64_t len = std::min<uint64_t>(want, r->fsize - r->fpos);
+        bool last_block = r->fpos + len >= r->fsize;
+        auto block = std::make_shared<std::vector<char>>(len);
+        uint64_t got = 0;
+        while (got < len) {
+            ssize_t k = pread(r->fd, block->data() + got, (size_t)std::min<uint64_t>(len - got, 1u << 30), (off_t)(r->fpos + got));
+            if (k < 0) {
+                if (errno == EINTR) continue;
+                smx_set_error(SMX_ERR_ARG, "read %s: %s", r->path.c_str(), strerror(errno));
+                return -1;
+            }
+            if (k == 0) break;
+            got += (uint64_t)k;
+        }
+        if (got < len) { len = got; last_block = true; block->resize(len); }
+        const char *base = block->data(), *end = base + len;
+        const int T = io_threads();
+        std::vector<const char *> cut(T + 1);
+        cut[0] = base;
+        cut[T] = end;
+        for (int t = 1; t < T; t++) {
+            const char *nominal = base + len * (uint64_t)t / (uint64_t)T;
+            const char *ls = nominal;   // back up to a line start
+            while (ls > base && ls[-1] != '\n') ls--;
+            cut[t] = find_record_start(ls, end);
+            if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+        }
+        std::vector<std::vector<Rec>> parts(T);
+        std::vector<const char *> stopped(T, nullptr);
+        std::vector<char> ok(T, 1);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t] {
+                if (cut[t] >= cut[t + 1]) { stopped[t] = cut[t]; return; }
+                ok[t] = parse_strict(base, cut[t], cut[t + 1], end, last_block, parts[t], &stopped[t]) ? 1 : 0;
+            });
+        for (auto &x : th) x.join();
+        for (int t = 0; t < T; t++) if (!ok[t]) return 0;
+        // parts must chain exactly (every cut is a genuine record start); only the part holding the block's last
+        // record may stop early, at the start of a record the block end cuts in two
+        const char *consumed = end;
+        bool tail_open = false;
+        for (int t = 0; t < T; t++) {
+            if (cut[t] >= cut[t + 1]) continue;
+            if (tail_open) { if (!parts[t].empty()) return 0; continue; }
+            if (stopped[t] == cut[t + 1]) continue;
+            if (stopped[t] < cut[t + 1]) { consumed = stopped[t]; tail_open = true; }
+            else return 0;
+        }
+        uint64_t total = 0;
+        for (auto &v : parts) total += v.size();
+        if (total == 0) {
+            if (last_block) {   // trailing blank lines / garbage: let the general engine judge it
+                bool blank = true;
+                for (const char *c = base; c < end; c++) if (!is_space((unsigned char)*c)) { blank = false; break; }
+                if (blank) { r->fpos = r->fsize; return 1; }
+                return 0;
+            }
+            want *= 2;          // one record larger than the block: retry with a bigger block
+            continue;
+        }
+        // keep at most max_reads records
+        uint64_t keep = std::min<uint64_t>(total, max_reads);
+        uint64_t next_off = (uint64_t)(consumed - base);
+        b->block = block;
+        uint64_t seen = 0;
+        for (int t = 0; t < T && seen < keep; t++) {
+            if (parts[t].empty()) continue;
+            uint64_t take = std::min<uint64_t>(parts[t].size(), keep - seen);
+            if (take < parts[t].size()) { next_off = parts[t][take].src_off; parts[t].resize(take); }
+            else if (seen + take == keep && keep < total) {
+                for (int u = t + 1; u < T; u++) if (!parts[u].empty()) { next_off = parts[u][0].src_off; break; }
+            }
+            b->segs.emplace_back();
+            b->segs.back().base = base;
+            b->segs.back().recs = std::move(parts[t]);
+            seen += take;
+        }
+        r->fpos += next_off;
+        return 1;
+    }
+}
 
 std::vector<std::string> split_names(const char *blob, const uint32_t *off, uint32_t n) {
     std::vector<std::string> v(n);
@@ -149,194 +404,78 @@ std::string safe_name(const std::string &s) {   // io_utils.py:207: chars outsid
 
 }  // namespace
 
-extern "C" {
+// ---------------------------------------------------------------- writer
+struct smx_writer {
+    std::string out_dir, prefix;
+    bool fastq = true;
+    std::vector<std::string> specimens, pools, primers, barcodes;
+    unsigned char comp[256];
+    struct File { std::string path; std::string pending; bool dir_made = false; };
+    struct Shard {   // one per writer thread: owns a disjoint set of output files
+        std::vector<File> files;
+        std::unordered_map<std::string, size_t> index;
+        std::string scratch;
+        int first_errno = 0;
+        int rc = 0;
+    };
+    std::vector<Shard> shards;
 
-int smx_reader_open(const char *path, smx_reader **out, int *is_fastq) {
-    if (!path || !out) return smx_set_error(SMX_ERR_ARG, "null argument");
-    // format by extension (compression suffixes stripped), then by first byte (io_utils.py:380-426)
-    std::string base(path);
-    size_t slash = base.find_last_of('/');
-    if (slash != std::string::npos) base = base.substr(slash + 1);
-    auto lower = [](std::string s) { for (char &c : s) c = (char)tolower((unsigned char)c); return s; };
-    auto ends = [](const std::string &s, const char *suf) { size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; };
-    std::string low = lower(base);
-    for (bool again = true; again;) {
-        again = false;
-        for (const char *ext : {".gz", ".gzip", ".bz2", ".zip"})
-            if (ends(low, ext)) { low.resize(low.size() - strlen(ext)); again = true; }
+    static void mkdirs(const std::string &path) {
+        for (size_t i = 1; i < path.size(); i++)
+            if (path[i] == '/') { std::string d = path.substr(0, i); mkdir(d.c_str(), 0777); }
     }
-    int fmt = 0;
-    if (ends(low, ".fastq") || ends(low, ".fq")) fmt = 1;
-    else if (ends(low, ".fasta") || ends(low, ".fa") || ends(low, ".fna")) fmt = 2;
-    gzFile gz = gzopen(path, "rb");
-    if (!gz) return smx_set_error(SMX_ERR_ARG, "cannot open %s: %s", path, strerror(errno));
-    gzbuffer(gz, 1u << 20);
-    smx_reader *r = new smx_reader();
-    r->gz = gz;
-    r->buf.resize(8u << 20);
-    if (fmt == 0) {
-        int c = r->peek();
-        fmt = (c == '@') ? 1 : 2;   // '>' or anything else: FASTA (the reference's default)
-    }
-    r->fastq = fmt == 1;
-    if (is_fastq) *is_fastq = r->fastq ? 1 : 0;
-    *out = r;
-    return SMX_OK;
-}
-
-void smx_reader_close(smx_reader *r) {
-    if (!r) return;
-    if (r->gz) gzclose(r->gz);
-    delete r;
-}
-
-smx_batch *smx_batch_new(void) { return new smx_batch(); }
-void smx_batch_free(smx_batch *b) { delete b; }
-uint32_t smx_batch_size(const smx_batch *b) { return b ? (uint32_t)b->recs.size() : 0; }
-
-int smx_batch_record(const smx_batch *b, uint32_t i, const char **id, uint32_t *id_len, const char **seq,
-                     const char **qual, uint32_t *seq_len) {
-    if (!b || i >= b->recs.size()) return smx_set_error(SMX_ERR_ARG, "record index out of range");
-    const Rec &r = b->recs[i];
-    if (id) *id = b->data.data() + r.id_off;
-    if (id_len) *id_len = r.id_len;
-    if (seq) *seq = b->data.data() + r.seq_off;
-    if (qual) *qual = r.qual_off == UINT64_MAX ? nullptr : b->data.data() + r.qual_off;
-    if (seq_len) *seq_len = r.seq_len;
-    return SMX_OK;
-}
-
-static void append_trimmed(std::vector<char> &dst, const char *p, size_t n, bool drop_inner_spaces) {
-    while (n && is_space((unsigned char)p[n - 1])) n--;
-    size_t a = 0;
-    while (a < n && is_space((unsigned char)p[a])) a++;
-    if (!drop_inner_spaces) { dst.insert(dst.end(), p + a, p + n); return; }
-    for (size_t i = a; i < n; i++) if (p[i] != ' ') dst.push_back(p[i]);
-}
-
-int smx_reader_next(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batch *b, uint32_t *n_read) {
-    if (!r || !b || !n_read) return smx_set_error(SMX_ERR_ARG, "null argument");
-    b->data.clear();
-    b->recs.clear();
-    const char *p;
-    size_t n;
-    while (b->recs.size() < max_reads && (max_bytes == 0 || b->data.size() < max_bytes)) {
-        if (r->fastq) {
-            // skip blank lines between records
-            bool have = false;
-            while ((have = r->next_line(&p, &n))) {
-                size_t k = n;
-                while (k && is_space((unsigned char)p[k - 1])) k--;
-                if (k) break;
-            }
-            if (!have) break;
-            if (p[0] != '@') return smx_set_error(SMX_ERR_ARG, "line %llu: Records in Fastq files should start with '@' character", (unsigned long long)r->line_no);
-            Rec rec;
-            // id = first whitespace-delimited word of the title
-            size_t a = 1;
-            while (a < n && is_space((unsigned char)p[a])) a++;
-            size_t e = a;
-            while (e < n && !is_space((unsigned char)p[e])) e++;
-            rec.id_off = b->data.size();
-            rec.id_len = (uint32_t)(e - a);
-            b->data.insert(b->data.end(), p + a, p + e);
-            // sequence lines until '+'
-            rec.seq_off = b->data.size();
-            bool plus = false;
-            while (r->next_line(&p, &n)) {
-                if (n && p[0] == '+') { plus = true; break; }
-                append_trimmed(b->data, p, n, false);
-            }
-            if (!plus) return smx_set_error(SMX_ERR_ARG, "line %llu: End of file without quality information.", (unsigned long long)r->line_no);
-            uint64_t slen = b->data.size() - rec.seq_off;
-            if (slen > 0x7FFFFFFFull) return smx_set_error(SMX_ERR_UNSUPPORTED, "read longer than 2^31-1 bases");
-            rec.seq_len = (uint32_t)slen;
-            // quality: one line always, then more while the next line is not a title of a complete record
-            rec.qual_off = b->data.size();
-            if (r->next_line(&p, &n)) append_trimmed(b->data, p, n, false);
-            for (;;) {
-                int c = r->peek();
-                if (c < 0) break;
-                uint64_t qlen = b->data.size() - rec.qual_off;
-                if (c == '@' && qlen >= slen) break;
-                if (!r->next_line(&p, &n)) break;
-                append_trimmed(b->data, p, n, false);
-            }
-            if (b->data.size() - rec.qual_off != slen)
-                return smx_set_error(SMX_ERR_ARG, "line %llu: Lengths of sequence and quality values differs (%llu and %llu).",
-                                     (unsigned long long)r->line_no, (unsigned long long)slen,
-                                     (unsigned long long)(b->data.size() - rec.qual_off));
-            b->recs.push_back(rec);
-        } else {
-            // FASTA: skip to the next '>' line
-            bool have = false;
-            while ((have = r->next_line(&p, &n))) if (n && p[0] == '>') break;
-            if (!have) break;
-            Rec rec;
-            size_t a = 1;
-            while (a < n && is_space((unsigned char)p[a])) a++;
-            size_t e = a;
-            while (e < n && !is_space((unsigned char)p[e])) e++;
-            rec.id_off = b->data.size();
-            rec.id_len = (uint32_t)(e - a);
-            b->data.insert(b->data.end(), p + a, p + e);
-            rec.seq_off = b->data.size();
-            for (;;) {
-                int c = r->peek();
-                if (c < 0 || c == '>') break;
-                if (!r->next_line(&p, &n)) break;
-                append_trimmed(b->data, p, n, true);
-            }
-            uint64_t slen = b->data.size() - rec.seq_off;
-            if (slen > 0x7FFFFFFFull) return smx_set_error(SMX_ERR_UNSUPPORTED, "read longer than 2^31-1 bases");
-            rec.seq_len = (uint32_t)slen;
-            rec.qual_off = UINT64_MAX;
-            b->recs.push_back(rec);
+    static void flush(Shard &sh, File &f) {
+        if (f.pending.empty()) return;
+        if (!f.dir_made) { mkdirs(f.path); f.dir_made = true; }
+        int fd = open(f.path.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0666);
+        if (fd < 0) { if (!sh.first_errno) sh.first_errno = errno; f.pending.clear(); return; }
+        const char *p = f.pending.data();
+        size_t left = f.pending.size();
+        while (left) {
+            ssize_t w = write(fd, p, left);
+            if (w < 0) { if (errno == EINTR) continue; if (!sh.first_errno) sh.first_errno = errno; break; }
+            p += w; left -= (size_t)w;
         }
+        close(fd);
+        f.pending.clear();
     }
-    *n_read = (uint32_t)b->recs.size();
-    return SMX_OK;
-}
-
-int smx_pack_windows_batch(const smx_batch *b, int32_t S, uint8_t *windows, int32_t *lens) {
-    if (!b || !windows || !lens || S < 1) return smx_set_error(SMX_ERR_ARG, "null argument");
-    const size_t stride = ((size_t)(2 * S) + 15) & ~(size_t)15;
-    const char *base = b->data.data();
-    for (size_t i = 0; i < b->recs.size(); i++) {
-        const Rec &r = b->recs[i];
-        int L = (int)r.seq_len, Sp = L < S ? L : S;
-        uint8_t *w = windows + i * stride;
-        memset(w, 0, stride);
-        memcpy(w, base + r.seq_off, (size_t)Sp);
-        memcpy(w + S, base + r.seq_off + (size_t)(L - Sp), (size_t)Sp);
-        lens[i] = L;
+    size_t file_for(Shard &sh, const std::string &rel) {
+        auto it = sh.index.find(rel);
+        if (it != sh.index.end()) return it->second;
+        sh.files.push_back(File{out_dir + "/" + rel, std::string(), false});
+        sh.index.emplace(rel, sh.files.size() - 1);
+        return sh.files.size() - 1;
     }
-    return SMX_OK;
+};
+
+namespace {
+
+inline uint32_t mix(uint32_t h, uint32_t v) { h ^= v + 0x9e3779b9u + (h << 6) + (h >> 2); return h; }
+
+// Which shard owns the primary / pool-level file of an operation (pure function of the file identity).
+inline void owners(const smx_op &op, uint32_t T, uint32_t *primary, uint32_t *pool_level) {
+    uint32_t cls = op.rtype == SMX_R_UNKNOWN ? 2u : ((op.rtype == SMX_R_PARTIAL_FWD || op.rtype == SMX_R_PARTIAL_REV) ? 1u : 0u);
+    uint32_t skey = op.sample >= 0 ? (uint32_t)op.sample
+                                   : (cls == 1 ? 0x40000000u + (uint32_t)(op.rtype == SMX_R_PARTIAL_REV) * 0x10000u + (uint32_t)(uint16_t)op.barcode
+                                               : 0x7FFFFFFFu);
+    uint32_t h = mix(mix(mix(mix(cls * 7919u, (uint32_t)(uint16_t)op.pool), (uint32_t)(uint16_t)op.p1), (uint32_t)(uint16_t)op.p2), skey);
+    *primary = h % T;
+    *pool_level = mix(mix(0xABCDu, (uint32_t)(uint16_t)op.pool), skey) % T;
 }
 
-int smx_writer_open(const char *output_dir, const char *prefix, int is_fastq, const smx_names *nm, smx_writer **out) {
-    if (!output_dir || !nm || !out) return smx_set_error(SMX_ERR_ARG, "null argument");
-    smx_writer *w = new smx_writer();
-    w->out_dir = output_dir;
-    w->prefix = prefix ? prefix : "";
-    w->fastq = is_fastq != 0;
-    w->specimens = split_names(nm->specimens, nm->specimen_off, nm->n_specimens);
-    w->pools = split_names(nm->pools, nm->pool_off, nm->n_pools);
-    w->primers = split_names(nm->primers, nm->primer_off, nm->n_primers);
-    w->barcodes = split_names(nm->barcodes, nm->barcode_off, nm->n_barcodes);
-    for (int c = 0; c < 256; c++) w->comp[c] = (unsigned char)c;
-    const char *from = "ACGTMRWSYKVHDBXNUacgtmrwsykvhdbxnu", *to = "TGCAKYWSRMBDHVXNAtgcakywsrmbdhvxna";
-    for (int i = 0; from[i]; i++) w->comp[(unsigned char)from[i]] = (unsigned char)to[i];
-    mkdir(output_dir, 0777);
-    *out = w;
-    return SMX_OK;
-}
-
-static int write_one(smx_writer *w, const smx_batch *b, const smx_op &op) {
+int write_one(smx_writer *w, smx_writer::Shard &sh, uint32_t me, uint32_t T, const smx_batch *b, const smx_op &op) {
     if (op.rtype == SMX_R_FILTERED) return SMX_OK;
-    if (op.read >= b->recs.size()) return smx_set_error(SMX_ERR_ARG, "write operation refers to read %u of %zu", op.read, b->recs.size());
-    const Rec &r = b->recs[op.read];
-    const char *base = b->data.data();
+    uint32_t o1, o2;
+    owners(op, T, &o1, &o2);
+    const bool full = op.rtype == SMX_R_FULL || op.rtype == SMX_R_DEREP_FULL;
+    const bool mine1 = o1 == me, mine2 = full && o2 == me;
+    if (!mine1 && !mine2) return SMX_OK;
+    if (op.read >= b->n) return smx_set_error(SMX_ERR_ARG, "write operation refers to read %u of %u", op.read, b->n);
+    const Segment *sg;
+    const Rec *rp;
+    b->locate(op.read, &sg, &rp);
+    const Rec &r = *rp;
+    const char *base = sg->base;
     auto name = [](const std::vector<std::string> &v, int i) -> const std::string & {
         static const std::string unknown = "unknown";
         return (i >= 0 && (size_t)i < v.size()) ? v[(size_t)i] : unknown;
@@ -351,7 +490,7 @@ static int write_one(smx_writer *w, const smx_batch *b, const smx_op &op) {
     if (s < 0) s = 0;   // the kernel only emits 0 <= s < e <= L for non-empty reads
     if (e > L) e = L;
     if (e < s) e = s;
-    std::string &rec = w->scratch;
+    std::string &rec = sh.scratch;
     rec.clear();
     rec.push_back(w->fastq ? '@' : '>');
     rec.append(base + r.id_off, r.id_len);
@@ -383,21 +522,173 @@ static int write_one(smx_writer *w, const smx_batch *b, const smx_op &op) {
     const char *top = op.rtype == SMX_R_UNKNOWN ? "unknown" : ((op.rtype == SMX_R_PARTIAL_FWD || op.rtype == SMX_R_PARTIAL_REV) ? "partial" : "full");
     const std::string ext = w->fastq ? ".fastq" : ".fasta";
     const std::string fname = w->prefix + safe_name(sample) + ext;
-    size_t f = w->file_for(std::string(top) + "/" + pool + "/" + p1 + "-" + p2 + "/" + fname);
-    w->files[f].pending += rec;
-    if (w->files[f].pending.size() > (256u << 10)) w->flush(w->files[f]);
-    if (op.rtype == SMX_R_FULL || op.rtype == SMX_R_DEREP_FULL) {   // pool-level aggregate (io_utils.py:256-268)
-        size_t g = w->file_for("full/" + pool + "/" + fname);
-        w->files[g].pending += rec;
-        if (w->files[g].pending.size() > (256u << 10)) w->flush(w->files[g]);
+    if (mine1) {
+        size_t f = w->file_for(sh, std::string(top) + "/" + pool + "/" + p1 + "-" + p2 + "/" + fname);
+        sh.files[f].pending += rec;
+        if (sh.files[f].pending.size() > (256u << 10)) smx_writer::flush(sh, sh.files[f]);
     }
+    if (mine2) {   // pool-level aggregate of full matches (io_utils.py:256-268)
+        size_t g = w->file_for(sh, "full/" + pool + "/" + fname);
+        sh.files[g].pending += rec;
+        if (sh.files[g].pending.size() > (256u << 10)) smx_writer::flush(sh, sh.files[g]);
+    }
+    return SMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smx_reader_open(const char *path, smx_reader **out, int *is_fastq) {
+    if (!path || !out) return smx_set_error(SMX_ERR_ARG, "null argument");
+    // format by extension (compression suffixes stripped), then by first byte (io_utils.py:380-426)
+    std::string base(path);
+    size_t slash = base.find_last_of('/');
+    if (slash != std::string::npos) base = base.substr(slash + 1);
+    auto ends = [](const std::string &s, const char *suf) { size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; };
+    std::string low = base;
+    for (char &c : low) c = (char)tolower((unsigned char)c);
+    bool compressed_name = false;
+    for (bool again = true; again;) {
+        again = false;
+        for (const char *ext : {".gz", ".gzip", ".bz2", ".zip"})
+            if (ends(low, ext)) { low.resize(low.size() - strlen(ext)); again = true; compressed_name = true; }
+    }
+    int fmt = 0;
+    if (ends(low, ".fastq") || ends(low, ".fq")) fmt = 1;
+    else if (ends(low, ".fasta") || ends(low, ".fa") || ends(low, ".fna")) fmt = 2;
+    gzFile gz = gzopen(path, "rb");
+    if (!gz) return smx_set_error(SMX_ERR_ARG, "cannot open %s: %s", path, strerror(errno));
+    gzbuffer(gz, 1u << 20);
+    smx_reader *r = new smx_reader();
+    r->path = path;
+    r->gz = gz;
+    r->buf.resize(8u << 20);
+    if (fmt == 0) {
+        int c = r->peek();
+        fmt = (c == '@') ? 1 : 2;   // '>' or anything else: FASTA (the reference's default)
+    }
+    r->fastq = fmt == 1;
+    // fast engine: uncompressed FASTQ only (gzdirect() is 1 when zlib is passing the bytes through)
+    (void)r->peek();
+    if (r->fastq && !compressed_name && gzdirect(gz) == 1 && !getenv("SMX_IO_SERIAL")) {
+        int fd = open(path, O_RDONLY);
+        struct stat st;
+        if (fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+            r->fd = fd;
+            r->fsize = (uint64_t)st.st_size;
+            r->fpos = 0;
+            r->fast = true;
+        } else if (fd >= 0) close(fd);
+    }
+    if (is_fastq) *is_fastq = r->fastq ? 1 : 0;
+    *out = r;
+    return SMX_OK;
+}
+
+void smx_reader_close(smx_reader *r) {
+    if (!r) return;
+    if (r->gz) gzclose(r->gz);
+    if (r->fd >= 0) close(r->fd);
+    delete r;
+}
+
+smx_batch *smx_batch_new(void) { return new smx_batch(); }
+void smx_batch_free(smx_batch *b) { delete b; }
+uint32_t smx_batch_size(const smx_batch *b) { return b ? b->n : 0; }
+
+int smx_batch_record(const smx_batch *b, uint32_t i, const char **id, uint32_t *id_len, const char **seq,
+                     const char **qual, uint32_t *seq_len) {
+    if (!b || i >= b->n) return smx_set_error(SMX_ERR_ARG, "record index out of range");
+    const Segment *sg;
+    const Rec *r;
+    b->locate(i, &sg, &r);
+    if (id) *id = sg->base + r->id_off;
+    if (id_len) *id_len = r->id_len;
+    if (seq) *seq = sg->base + r->seq_off;
+    if (qual) *qual = r->qual_off == UINT64_MAX ? nullptr : sg->base + r->qual_off;
+    if (seq_len) *seq_len = r->seq_len;
+    return SMX_OK;
+}
+
+int smx_reader_next(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batch *b, uint32_t *n_read) {
+    if (!r || !b || !n_read) return smx_set_error(SMX_ERR_ARG, "null argument");
+    b->clear();
+    *n_read = 0;
+    if (max_reads == 0) return SMX_OK;
+    if (r->fast) {
+        int rc = next_fast(r, max_reads, max_bytes, b);
+        if (rc < 0) return SMX_ERR_ARG;
+        if (rc == 0) {   // irregular FASTQ: continue with the general engine from this block's start, for good
+            b->clear();
+            r->fast = false;
+            if (gzseek(r->gz, (z_off_t)r->fpos, SEEK_SET) < 0)
+                return smx_set_error(SMX_ERR_ARG, "cannot seek in %s", r->path.c_str());
+            r->pos = r->end = 0;
+            r->eof = false;
+        }
+    }
+    if (!r->fast) {
+        int rc = next_general(r, max_reads, max_bytes, b);
+        if (rc) return rc;
+    }
+    b->finish();
+    *n_read = b->n;
+    return SMX_OK;
+}
+
+int smx_pack_windows_batch(const smx_batch *b, int32_t S, uint8_t *windows, int32_t *lens) {
+    if (!b || !windows || !lens || S < 1) return smx_set_error(SMX_ERR_ARG, "null argument");
+    const size_t stride = ((size_t)(2 * S) + 15) & ~(size_t)15;
+    const int T = (int)std::min<size_t>((size_t)io_threads(), std::max<size_t>(b->segs.size(), 1));
+    std::atomic<size_t> next(0);
+    auto work = [&] {
+        for (size_t k = next.fetch_add(1); k < b->segs.size(); k = next.fetch_add(1)) {
+            const Segment &sg = b->segs[k];
+            for (size_t j = 0; j < sg.recs.size(); j++) {
+                const Rec &r = sg.recs[j];
+                size_t i = (size_t)b->first[k] + j;
+                int L = (int)r.seq_len, Sp = L < S ? L : S;
+                uint8_t *w = windows + i * stride;
+                memset(w, 0, stride);
+                memcpy(w, sg.base + r.seq_off, (size_t)Sp);
+                memcpy(w + S, sg.base + r.seq_off + (size_t)(L - Sp), (size_t)Sp);
+                lens[i] = L;
+            }
+        }
+    };
+    if (T <= 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(work);
+        for (auto &x : th) x.join();
+    }
+    return SMX_OK;
+}
+
+int smx_writer_open(const char *output_dir, const char *prefix, int is_fastq, const smx_names *nm, smx_writer **out) {
+    if (!output_dir || !nm || !out) return smx_set_error(SMX_ERR_ARG, "null argument");
+    smx_writer *w = new smx_writer();
+    w->out_dir = output_dir;
+    w->prefix = prefix ? prefix : "";
+    w->fastq = is_fastq != 0;
+    w->specimens = split_names(nm->specimens, nm->specimen_off, nm->n_specimens);
+    w->pools = split_names(nm->pools, nm->pool_off, nm->n_pools);
+    w->primers = split_names(nm->primers, nm->primer_off, nm->n_primers);
+    w->barcodes = split_names(nm->barcodes, nm->barcode_off, nm->n_barcodes);
+    for (int c = 0; c < 256; c++) w->comp[c] = (unsigned char)c;
+    const char *from = "ACGTMRWSYKVHDBXNUacgtmrwsykvhdbxnu", *to = "TGCAKYWSRMBDHVXNAtgcakywsrmbdhvxna";
+    for (int i = 0; from[i]; i++) w->comp[(unsigned char)from[i]] = (unsigned char)to[i];
+    w->shards.resize((size_t)io_threads());
+    mkdir(output_dir, 0777);
+    *out = w;
     return SMX_OK;
 }
 
 int smx_writer_write(smx_writer *w, const smx_batch *b, const smx_op *ops, uint32_t n_reads, const smx_op *extra,
                      uint32_t n_extra) {
     if (!w || !b || !ops) return smx_set_error(SMX_ERR_ARG, "null argument");
-    if (n_reads != b->recs.size()) return smx_set_error(SMX_ERR_ARG, "ops for %u reads, batch holds %zu", n_reads, b->recs.size());
+    if (n_reads != b->n) return smx_set_error(SMX_ERR_ARG, "ops for %u reads, batch holds %u", n_reads, b->n);
     // extra records grouped by read, emission order kept (stable counting sort on the read index)
     std::vector<uint32_t> first(n_reads + 1, 0), order(n_extra);
     for (uint32_t j = 0; j < n_extra; j++) {
@@ -409,23 +700,39 @@ int smx_writer_write(smx_writer *w, const smx_batch *b, const smx_op *ops, uint3
         std::vector<uint32_t> fill(first.begin(), first.end() - 1);
         for (uint32_t j = 0; j < n_extra; j++) order[fill[extra[j].read]++] = j;
     }
-    for (uint32_t i = 0; i < n_reads; i++) {
-        smx_op op = ops[i];
-        op.read = i;
-        int rc = write_one(w, b, op);
-        if (rc) return rc;
-        for (uint32_t k = first[i]; k < first[i + 1]; k++) {
-            rc = write_one(w, b, extra[order[k]]);
-            if (rc) return rc;
+    // every shard (thread) walks all operations in read order and writes the ones whose file it owns: per-file
+    // record order is the input order, no locks
+    const uint32_t T = (uint32_t)w->shards.size();
+    std::vector<std::string> errs(T);
+    auto work = [&](uint32_t me) {
+        smx_writer::Shard &sh = w->shards[me];
+        sh.rc = 0;
+        for (uint32_t i = 0; i < n_reads && !sh.rc; i++) {
+            smx_op op = ops[i];
+            op.read = i;
+            sh.rc = write_one(w, sh, me, T, b, op);
+            for (uint32_t k = first[i]; k < first[i + 1] && !sh.rc; k++) sh.rc = write_one(w, sh, me, T, b, extra[order[k]]);
         }
+        if (sh.rc) errs[me] = smx_last_error();
+    };
+    if (T <= 1 || n_reads < 512) { for (uint32_t t = 0; t < T; t++) work(t); }
+    else {
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < T; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
     }
+    for (uint32_t t = 0; t < T; t++)
+        if (w->shards[t].rc) return smx_set_error(w->shards[t].rc, "%s", errs[t].c_str());
     return SMX_OK;
 }
 
 int smx_writer_close(smx_writer *w) {
     if (!w) return SMX_OK;
-    for (auto &f : w->files) w->flush(f);
-    int err = w->first_errno;
+    int err = 0;
+    for (auto &sh : w->shards) {
+        for (auto &f : sh.files) smx_writer::flush(sh, f);
+        if (!err) err = sh.first_errno;
+    }
     delete w;
     if (err) return smx_set_error(SMX_ERR_ARG, "output write failed: %s", strerror(err));
     return SMX_OK;

@@ -13,7 +13,7 @@ from . import _lib
 from .native_io import Reader, Writer
 
 BATCH_READS = 131072          # reads per kernel launch
-BATCH_BYTES = 512 << 20       # ... or this many bytes of parsed records, whichever comes first
+BATCH_BYTES = 256 << 20       # ... or this many bytes of input, whichever comes first
 
 
 def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seqs=-1, on_batch=None):

@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=N_READS, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3"], help=argparse.SUPPRESS)   # c3: 3072 specimens / 4 pools
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -111,7 +112,7 @@ def main():
         a.gpus = world
 
     from specimux_amd import synth
-    pan = synth.panel_c2(SEED)
+    pan = synth.panel_c2(SEED) if a.config == "c2" else synth.panel_c3(SEED)
     tmp = tempfile.mkdtemp(prefix="smx_bench_")
     pf, sf = pan.write(tmp)
     from specimux_amd.distributed import shard_seed
@@ -147,7 +148,7 @@ def main():
     parameters = sa.setup_match_parameters(args, specimens)
     prefilter = BloomPrefilter(barcodes_for_bloom_prefilter(specimens), parameters.max_dist_index)
     cp = compiled_panel(specimens, parameters, args, prefilter)
-    assert parameters.max_dist_index == 3 and len(cp.specimen_ids) == 768
+    assert parameters.max_dist_index == 3 and len(cp.specimen_ids) == (768 if a.config == "c2" else 3072)
 
     n = a.reads
     d_windows = torch.from_numpy(rs.windows(cp.window_stride)).to(dev)
@@ -222,9 +223,10 @@ def main():
         "value": total_reads / elapsed, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "configs[1]: 768-specimen ONT037-style ITS panel (32x24 13-nt barcodes, ITS1F/ITS4, "
-                               "k_idx=3, k_p=7/6), 765k reads per GPU per step, search_len 80, prefilter+preorient on, "
-                               "trim=barcodes, dereplicate=best",
+        "config": {"workload": ("configs[1]: 768-specimen ONT037-style ITS panel (32x24 13-nt barcodes, ITS1F/ITS4, "
+                                "k_idx=3, k_p=7/6), 765k reads per GPU per step, search_len 80, prefilter+preorient on, "
+                                "trim=barcodes, dereplicate=best") if a.config == "c2" else
+                               "configs[2]-style: 3072 specimens over 4 pools (ITS/RPB2/LSU/TEF1, ITS4 shared), default flags",
                    "reads_per_gpu_per_step": n, "seed": SEED, "parallelism": f"read-sharded x{world}",
                    "matched_fraction": float(matched)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

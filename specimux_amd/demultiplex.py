@@ -31,14 +31,14 @@ def _prefilter_enabled(prefilter) -> bool:
 
 def compiled_panel(specimens, parameters, args, prefilter) -> CompiledPanel:
     """One CompiledPanel per distinct (panel, thresholds, flags); cached on the Specimens object."""
-    key = (id(parameters), parameters.max_dist_index, parameters.search_len, parameters.preorient,
+    key = (parameters.max_dist_index, parameters.search_len, parameters.preorient,
            tuple(sorted(parameters.max_dist_primers.items())), getattr(args, "trim", TrimMode.BARCODES),
            getattr(args, "dereplicate", MultipleMatchStrategy.BEST), _prefilter_enabled(prefilter),
            getattr(args, "min_length", -1), getattr(args, "max_length", -1), len(specimens._specimens))
     cache = specimens.__dict__.setdefault("_smx_panels", {})
     if key not in cache:
-        cache[key] = CompiledPanel(specimens, parameters, trim=key[5], dereplicate=key[6], prefilter=key[7],
-                                   min_length=key[8], max_length=key[9])
+        cache[key] = CompiledPanel(specimens, parameters, trim=key[4], dereplicate=key[5], prefilter=key[6],
+                                   min_length=key[7], max_length=key[8])
     return cache[key]
 
 

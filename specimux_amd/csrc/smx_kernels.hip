@@ -228,24 +228,33 @@ __device__ __forceinline__ int nth_location(const unsigned *mrow, int MW, int js
 // with SHW boundaries D[0][j] = j, D[i][0] = i.  D[m][c] is kept as a bit-sliced 5-bit counter; seen[d] collects
 // the barcodes whose last-row score equalled d (<= k) at some column: exactly what the per-hit distance-level
 // bitmasks of the lean summary need (the lowest non-empty level is the best distance, its bits are the tie set).
+// Ukkonen band: an alignment of cost <= k never leaves the cells with |column - row| <= k, so only those are
+// computed (banded values D' >= D, and D' == D wherever D <= k -- all that seen[] needs).  No boundary special
+// cases are required: a row below the band has never been touched and still holds its initial vertical delta
+// (+1), which is what "left neighbour = infinity" means for the cell that enters the band; the top in-band cell
+// takes (+1) as horizontal delta from above, like row 0 does.  The tracked score B_c = D'(bottom in-band row, c):
+// while the band's bottom edge is still descending (c + k <= m - 1) the bottom cell has no left neighbour and
+// B_c = B_(c-1) + (1 - Z); once it sits on the last row, B_c = B_(c-1) + (Ph - Mh) as in the full DP.  B_0 = k.
 template <int KL>   // KL = number of distance levels kept (k + 1 <= KL): 4 or 8
 __device__ __forceinline__ void bitsliced_shw(const unsigned *re, int MBW, const unsigned char *cw, int ncol, int m,
                                               int kidx, unsigned (&seen)[KL]) {
     unsigned Pv[16], Mv[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) { Pv[i] = ~0u; Mv[i] = 0u; }
-    unsigned s0 = (m & 1) ? ~0u : 0u, s1 = (m & 2) ? ~0u : 0u, s2 = (m & 4) ? ~0u : 0u, s3 = (m & 8) ? ~0u : 0u,
-             s4 = (m & 16) ? ~0u : 0u;
+    const int b0 = kidx < m ? kidx : m;   // D(bottom row of column 0)
+    unsigned s0 = (b0 & 1) ? ~0u : 0u, s1 = (b0 & 2) ? ~0u : 0u, s2 = (b0 & 4) ? ~0u : 0u, s3 = (b0 & 8) ? ~0u : 0u,
+             s4 = (b0 & 16) ? ~0u : 0u;
 #pragma unroll
     for (int d = 0; d < KL; d++) seen[d] = 0u;
     const int ncols = m + kidx, rs = 16 * MBW;
     for (int c = 0; c < ncols; c++) {
         const unsigned code = c < ncol ? (unsigned)cw[c] : 15u;   // past the window: code 15 matches nothing
         const unsigned *rc = re + code * MBW;
-        unsigned Ph = ~0u, Mh = 0u;
+        const int rlo = c - kidx, rhi = (c + kidx < m - 1) ? c + kidx : m - 1;   // in-band rows of this column
+        unsigned Ph = ~0u, Mh = 0u, Zb = 0u;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            if (i < m) {
+            if (i >= rlo && i <= rhi) {
                 const unsigned Eq = rc[i * rs];
                 const unsigned Z = Eq | Mh | Mv[i];
                 const unsigned nPh = Mv[i] | ~(Z | Pv[i]);
@@ -253,23 +262,27 @@ __device__ __forceinline__ void bitsliced_shw(const unsigned *re, int MBW, const
                 const unsigned nPv = Mh | ~(Z | Ph);
                 const unsigned nMv = Ph & Z;
                 Pv[i] = nPv; Mv[i] = nMv; Ph = nPh; Mh = nMh;
+                Zb = Z;   // the last executed row's Z (rhi)
             }
         }
-        {   // score += Ph - Mh (disjoint masks), ripple through the five planes
-            unsigned cy = Ph, t;
+        unsigned inc, dec;
+        if (c + kidx <= m - 1) { inc = ~Zb; dec = 0u; }   // bottom edge still descending: +1 unless the diagonal is free
+        else { inc = Ph; dec = Mh; }                      // on the last row: horizontal delta of row m
+        {   // score += inc - dec (disjoint masks), ripple through the five planes
+            unsigned cy = inc, t;
             t = s0 & cy; s0 ^= cy; cy = t;
             t = s1 & cy; s1 ^= cy; cy = t;
             t = s2 & cy; s2 ^= cy; cy = t;
             t = s3 & cy; s3 ^= cy; cy = t;
             s4 ^= cy;
-            unsigned bw = Mh;
+            unsigned bw = dec;
             t = ~s0 & bw; s0 ^= bw; bw = t;
             t = ~s1 & bw; s1 ^= bw; bw = t;
             t = ~s2 & bw; s2 ^= bw; bw = t;
             t = ~s3 & bw; s3 ^= bw; bw = t;
             s4 ^= bw;
         }
-        if (c >= m - kidx - 1) {   // a score <= k needs at least m - k consumed columns
+        if (c >= m - kidx - 1) {   // the tracked cell is on the last row from here on
             const unsigned live = c < ncol ? ~0u : 0u;
             const unsigned hi = ~(s4 | s3) & live;
 #pragma unroll

@@ -148,6 +148,46 @@ def create_output_files(args, specimens):
                 os.makedirs(os.path.join(out, kind, pool, f"unknown-{r.name}"), exist_ok=True)
 
 
+def subsample_top_quality(output_dir: str, top_n: int):
+    """--sample-topq N: for every FASTQ under full/, write subsample/<same path> with the N records of highest mean
+    Phred quality (stable order on ties) and copy the primer side files (reference: orchestration.py:374-445)."""
+    import shutil
+    from .io_utils import parse_fastq
+    full_dir = os.path.join(output_dir, "full")
+    if not os.path.exists(full_dir):
+        logging.warning(f"Full directory not found: {full_dir}")
+        return
+    logging.info(f"Creating subsamples with top {top_n} sequences by quality...")
+    done = failed = 0
+    for root, _dirs, files in os.walk(full_dir):
+        for fname in files:
+            if not fname.endswith(".fastq"):
+                continue
+            dest_dir = os.path.join(output_dir, "subsample", os.path.relpath(root, full_dir))
+            os.makedirs(dest_dir, exist_ok=True)
+            for side in ("primers.fasta", "primers.txt"):
+                if os.path.exists(os.path.join(root, side)):
+                    shutil.copy2(os.path.join(root, side), os.path.join(dest_dir, side))
+            try:
+                with open(os.path.join(root, fname)) as fh:
+                    records = list(parse_fastq(fh))
+                if not records:
+                    continue
+
+                def mean_q(rec):
+                    q = rec.quality_string
+                    return (sum(map(ord, q)) / len(q) - 33) if q else 0
+                records.sort(key=mean_q, reverse=True)
+                with open(os.path.join(dest_dir, fname), "w") as out:
+                    for rec in records[:top_n]:
+                        out.write(f"@{rec.description}\n{rec.seq}\n+\n{rec.quality_string}\n")
+                done += 1
+            except Exception as e:
+                logging.warning(f"Failed to subsample {os.path.join(root, fname)}: {e}")
+                failed += 1
+    logging.info(f"Subsampling complete: {done} files processed, {failed} failed")
+
+
 def iter_batches(seq_records, batch_size: int, max_seqs: int, all_seqs: bool):
     done = 0
     while all_seqs or done < max_seqs:
@@ -190,6 +230,8 @@ def _run_native(args):
                                                  start_seq=args.start_seq, num_seqs=args.num_seqs)
     _finish(total, matched, start)
     cleanup_empty_directories(args.output_dir)
+    if getattr(args, "sample_topq", 0) > 0:
+        subsample_top_quality(args.output_dir, args.sample_topq)
     cleanup_locks(args.output_dir)
 
 

@@ -157,3 +157,16 @@ def test_bloom_prefilter_exact_set_rule_matches_oracle():
             t = "ACGTACGTTGCAA"[rnd.randint(0, 3):] + t
         for b in mine.barcodes:
             assert mine.match(b, t) == theirs.match(b, t), (b, t)
+
+
+def test_subsample_top_quality(tmp_path):
+    from specimux_amd.orchestration import subsample_top_quality
+    d = tmp_path / "out" / "full" / "P" / "F-R"
+    d.mkdir(parents=True)
+    (d / "primers.fasta").write_text(">F\nACGT\n")
+    recs = [("a", "ACGT", "IIII"), ("b", "ACGT", "####"), ("c", "AC", "5I"), ("d", "ACGT", "IIII")]
+    (d / "s.fastq").write_text("".join(f"@{i} 0,0,0,0 pool=P primers=F+R s\n{s}\n+\n{q}\n" for i, s, q in recs))
+    subsample_top_quality(str(tmp_path / "out"), 2)
+    got = (tmp_path / "out" / "subsample" / "P" / "F-R" / "s.fastq").read_text()
+    assert got == "@a 0,0,0,0 pool=P primers=F+R s\nACGT\n+\nIIII\n@d 0,0,0,0 pool=P primers=F+R s\nACGT\n+\nIIII\n"
+    assert (tmp_path / "out" / "subsample" / "P" / "F-R" / "primers.fasta").exists()

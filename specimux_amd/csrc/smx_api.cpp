@@ -290,13 +290,14 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     size_t budget = 40 * 1024;   // 4 workgroups per CU (VGPR-limited to 4 waves/SIMD anyway)
     if (const char *e = getenv("SMX_LDS_BUDGET")) budget = (size_t)atol(e);
     int rmax = 64;
-    if (const char *e = getenv("SMX_TILE_R")) rmax = std::max(1, std::min(64, atoi(e)));
+    if (const char *e = getenv("SMX_TILE_R")) rmax = std::max(1, std::min(128, atoi(e)));
     const int npmeta = 5 * NP + 1 + h.n_pbc + NB + 3 * NPAIR;
     for (int slots = 0; slots < 2; slots++)
         for (int R = rmax; R >= 1; R >>= 1) {
             size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, slots,
                                               h.bs_ok);
-            if (need <= budget || R == 1) {
+            // 128-read tiles run on 512-thread workgroups: two of those per CU
+            if (need <= (R > 64 ? 2 * budget : budget) || R == 1) {
                 if (slots) { P->R_slots = R; P->lds_slots = need; } else { P->R = R; P->lds = need; }
                 break;
             }

@@ -721,8 +721,8 @@ __device__ inline void score_general(Emitter &E, int ori) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename PW>
-__global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
+template <typename PW, int NT>   // NT threads per workgroup: 256 (tiles up to 64 reads) or 512 (128 reads)
+__global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
@@ -762,19 +762,19 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
     const int CS = T.CS, NPs = T.NPs, NBs = T.NBs, lNPs = T.lNPs, lNBs = T.lNBs, G = T.G, logG = T.logG, MBW = T.MBW;
 
     // ---- phase 0: stage the panel (transposed: consecutive lanes = consecutive patterns hit distinct banks)
-    for (int i = tid; i < NP * 16; i += 256) {
+    for (int i = tid; i < NP * 16; i += NT) {
         int p = i >> 4, c = i & 15;
         ppeq[c * NPs + p] = (PW)P->ppeq[i];
         if (P->need_starts) prpeq[c * NPs + p] = (PW)P->prpeq[i];
     }
     if (!use_bs)
-        for (int i = tid; i < NB * 16; i += 256) bpeq[(i & 15) * NBs + (i >> 4)] = P->bpeq[i];
+        for (int i = tid; i < NB * 16; i += NT) bpeq[(i & 15) * NBs + (i >> 4)] = P->bpeq[i];
     if (use_bs)
-        for (int i = tid; i < NP * 16 * 16 * T.MBW; i += 256) {
+        for (int i = tid; i < NP * 16 * 16 * T.MBW; i += NT) {
             int p = i / (256 * T.MBW);
             bsre[p * T.BSP + (i - p * 256 * T.MBW)] = P->bs_re[i];
         }
-    for (int i = tid; i < 512; i += 256) lut[i] = P->lut[i];
+    for (int i = tid; i < 512; i += NT) lut[i] = P->lut[i];
     int *pmeta = (int *)(lds + T.pmeta);
     LPanel LP;
     {
@@ -782,13 +782,13 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
         LP.pm = q; q += NP; LP.pk = q; q += NP; LP.pdir = q; q += NP; LP.pfidx = q; q += NP;
         LP.pbc_off = q; q += NP + 1; LP.pbc = q; q += n_pbc; LP.bm = q; q += NB;
         LP.pair_f = q; q += NPAIR; LP.pair_r = q; q += NPAIR; LP.pair_pool = q;
-        for (int i = tid; i < NP; i += 256) {
+        for (int i = tid; i < NP; i += NT) {
             pmeta[i] = P->pm[i]; pmeta[NP + i] = P->pk[i]; pmeta[2 * NP + i] = P->pdir[i]; pmeta[3 * NP + i] = P->pfidx[i];
         }
-        for (int i = tid; i <= NP; i += 256) pmeta[4 * NP + i] = P->pbc_off[i];
-        for (int i = tid; i < n_pbc; i += 256) pmeta[5 * NP + 1 + i] = P->pbc[i];
-        for (int i = tid; i < NB; i += 256) pmeta[5 * NP + 1 + n_pbc + i] = P->bm[i];
-        for (int i = tid; i < NPAIR; i += 256) {
+        for (int i = tid; i <= NP; i += NT) pmeta[4 * NP + i] = P->pbc_off[i];
+        for (int i = tid; i < n_pbc; i += NT) pmeta[5 * NP + 1 + i] = P->pbc[i];
+        for (int i = tid; i < NB; i += NT) pmeta[5 * NP + 1 + n_pbc + i] = P->bm[i];
+        for (int i = tid; i < NPAIR; i += NT) {
             int *b = pmeta + 5 * NP + 1 + n_pbc + NB;
             b[i] = P->pair_f[i]; b[NPAIR + i] = P->pair_r[i]; b[2 * NPAIR + i] = P->pair_pool[i];
         }
@@ -819,12 +819,12 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
 
         // ---- phase 1: windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
         if (tid < nr) { lensL[tid] = lens[r0 + tid]; ocnt[2 * tid] = 0; ocnt[2 * tid + 1] = 0; }
-        for (int i = tid; i < nr * 2 * (MW + 1); i += 256) namask[i] = 0;
+        for (int i = tid; i < nr * 2 * (MW + 1); i += NT) namask[i] = 0;
         __syncthreads();
         {
             const int chunks = stride / 16;
             const uint4 *src = (const uint4 *)(windows + (size_t)r0 * stride);
-            for (int ci = tid; ci < nr * chunks; ci += 256) {
+            for (int ci = tid; ci < nr * chunks; ci += NT) {
                 int r = ci / chunks, cpos = (ci - r * chunks) * 16;
                 uint4 v = src[ci];
                 int L = lensL[r];
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
         STAMP(0);
 
         // ---- phase 2: primer scan, one lane per (read, primer, end)
-        for (int item = tid; item < nh; item += 256) {
+        for (int item = tid; item < nh; item += NT) {
             int r = item / H, h = item - r * H, p = h >> 1, X = h & 1;
             int L = lensL[r];
             EndGeom g = end_geom(L, S);
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
         STAMP(1);
 
         // ---- phase 3a: orientation, which ends need barcodes; scans of locations (A) and searched hits (B)
-        for (int item = tid; item < nh; item += 256) {
+        for (int item = tid; item < nh; item += NT) {
             int r = item / H, h = item - r * H, p = h >> 1, X = h & 1;
             int L = lensL[r];
             int f = ocnt[2 * r], rv = ocnt[2 * r + 1];
@@ -976,12 +976,12 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
             for (int w = 0; w < MBW; w++) tiem[item * MBW + w] = 0;
         }
         if (dbg_bdist)
-            for (int i = tid; i < nh * maxB; i += 256) dbg_bdist[(size_t)r0 * H * maxB + i] = -1;
+            for (int i = tid; i < nh * maxB; i += NT) dbg_bdist[(size_t)r0 * H * maxB + i] = -1;
         __syncthreads();
         if (wave == 0) wave_exclusive_scan(offsA, nh);
         else if (wave == 1) wave_exclusive_scan(offsB, nh);
         __syncthreads();
-        for (int item = tid; item < nh; item += 256)
+        for (int item = tid; item < nh; item += NT)
             if (offsB[item + 1] != offsB[item]) queue[offsB[item]] = (unsigned short)item;
         const int nq = offsB[nh];
         __syncthreads();
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
             const int e_end = (q1 < nq) ? offsA[queue[q1]] : offsA[nh];
             const int nE = e_end - e_base;
             // entries: one thread per searched hit of the round lists its optimal locations
-            for (int q = q0 + tid; q < q1; q += 256) {
+            for (int q = q0 + tid; q < q1; q += NT) {
                 int item = queue[q];
                 int r = item / H, h = item - r * H, X = h & 1;
                 const HitL &hl = hits[item];
@@ -1050,15 +1050,15 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                     }
                 }
             }
-            if (use_slots) { for (int i = tid; i < ((q1 - q0) << logG); i += 256) bres[i] = 0xFFFFFFFFu; }
-            else { for (int i = tid; i < (q1 - q0) * (kidx + 1) * MBW; i += 256) dmask[i] = 0; }
+            if (use_slots) { for (int i = tid; i < ((q1 - q0) << logG); i += NT) bres[i] = 0xFFFFFFFFu; }
+            else { for (int i = tid; i < (q1 - q0) * (kidx + 1) * MBW; i += NT) dmask[i] = 0; }
             __syncthreads();
             STAMP(3);
 
             // 3b (lean, uniform barcode length): bit-sliced scan, one lane per (entry, 32-barcode word)
             if (use_bs) {
                 const int bsm = P->bs_m;
-                for (int item = tid; item < nE * MBW; item += 256) {
+                for (int item = tid; item < nE * MBW; item += NT) {
                     const int ei = item / MBW, w = item - ei * MBW;
                     const EntL en = ents[ei];
                     if (!en.ok) continue;
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                 }
             } else
             // 3b: barcode scan, one lane per (entry, barcode slot)
-            for (int item = tid; item < (nE << logG); item += 256) {
+            for (int item = tid; item < (nE << logG); item += NT) {
                 const EntL en = ents[item >> logG];
                 int bi = item & (G - 1);
                 int hh = en.hit, h = hh % H, p = h >> 1, X = h & 1, r = hh / H;
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
             // group-of-G reductions by xor-shuffles, the tie bitmask straight from the ballot.
             if (!use_slots) {
                 // lean mode: best = lowest distance level with any barcode, tie set = that level's bitmask
-                for (int q = q0 + tid; q < q1; q += 256) {
+                for (int q = q0 + tid; q < q1; q += NT) {
                     int item = queue[q];
                     const unsigned *dm = dmask + (q - q0) * (kidx + 1) * MBW;
                     for (int d = 0; d <= kidx; d++) {
@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                 }
             } else if (G <= 64) {
                 const int nslots = (q1 - q0) << logG;
-                for (int base_i = wave * 64; base_i < nslots; base_i += 256) {
+                for (int base_i = wave * 64; base_i < nslots; base_i += NT) {
                     const int i = base_i + (tid & 63);
                     const bool in = i < nslots;
                     const int q = q0 + ((in ? i : 0) >> logG), sl = i & (G - 1);
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
                     }
                 }
             } else
-            for (int q = q0 + tid; q < q1; q += 256) {
+            for (int q = q0 + tid; q < q1; q += NT) {
                 int item = queue[q];
                 HitL &hl = hits[item];
                 int r = item / H, h = item - r * H, p = h >> 1;
@@ -1282,11 +1282,11 @@ __global__ __launch_bounds__(256, 4) void demux_kernel(DevPanel Pv, const uint8_
         {
             const uint4 *srcv = (const uint4 *)opsL;
             uint4 *dstv = (uint4 *)(ops + r0);
-            for (int i = tid; i < nr * 2; i += 256) dstv[i] = srcv[i];
+            for (int i = tid; i < nr * 2; i += NT) dstv[i] = srcv[i];
         }
         // ---- optional parity dump
         if (dbg_hits) {
-            for (int item = tid; item < nh; item += 256) {
+            for (int item = tid; item < nh; item += NT) {
                 int r = item / H;
                 const HitL &hl = hits[item];
                 EndGeom g = end_geom(lensL[r], S);
@@ -1394,14 +1394,14 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
     // d_tile_counter[0] = tile queue head, [1] = number of deferred reads
     hipError_t me = hipMemsetAsync(d_tile_counter, 0, 2 * sizeof(unsigned), s);
     if (me != hipSuccess) return (int)me;
-    if (use64)
-        hipLaunchKernelGGL(smx::demux_kernel<unsigned long long>, dim3(grid), dim3(256), lds_bytes, s, *P, d_windows,
-                           d_lens, n_reads, R, d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts,
-                           d_hits, d_bdist, d_tile_counter, use_slots, d_defer, d_tile_counter + 1);
-    else
-        hipLaunchKernelGGL(smx::demux_kernel<unsigned>, dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens,
-                           n_reads, R, d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits,
-                           d_bdist, d_tile_counter, use_slots, d_defer, d_tile_counter + 1);
+    // tiles of up to 64 reads run on 256-thread workgroups, tiles of 128 reads on 512-thread workgroups
+#define SMX_LAUNCH(PWT, NTV)                                                                                          \
+    hipLaunchKernelGGL((smx::demux_kernel<PWT, NTV>), dim3(grid), dim3(NTV), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
+                       d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits, d_bdist,        \
+                       d_tile_counter, use_slots, d_defer, d_tile_counter + 1)
+    if (R > 64) { if (use64) SMX_LAUNCH(unsigned long long, 512); else SMX_LAUNCH(unsigned, 512); }
+    else { if (use64) SMX_LAUNCH(unsigned long long, 256); else SMX_LAUNCH(unsigned, 256); }
+#undef SMX_LAUNCH
     me = hipGetLastError();
     if (me != hipSuccess) return (int)me;
     // general scorer over the deferred reads (usually well under 1 %): ordered after the main kernel on the stream
@@ -1418,10 +1418,13 @@ extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, i
 }
 
 extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
-    hipError_t e = use64 ? hipFuncSetAttribute((const void *)smx::demux_kernel<unsigned long long>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
-                         : hipFuncSetAttribute((const void *)smx::demux_kernel<unsigned>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipError_t e = hipSuccess;
+    const void *fns[2] = {use64 ? (const void *)smx::demux_kernel<unsigned long long, 256> : (const void *)smx::demux_kernel<unsigned, 256>,
+                          use64 ? (const void *)smx::demux_kernel<unsigned long long, 512> : (const void *)smx::demux_kernel<unsigned, 512>};
+    for (const void *f : fns) {
+        hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (r != hipSuccess) e = r;
+    }
     return (int)e;
 }
 
@@ -1430,8 +1433,8 @@ extern "C" size_t smx_deferred_rec_bytes(int NP, int maxB) {   // 0: the build k
 }
 
 extern "C" int smx_query_occupancy(int use64, size_t lds_bytes, int *blocks_per_cu) {
-    hipError_t e = use64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, smx::demux_kernel<unsigned long long>, 256, lds_bytes)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, smx::demux_kernel<unsigned>, 256, lds_bytes);
+    hipError_t e = use64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, smx::demux_kernel<unsigned long long, 256>, 256, lds_bytes)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, smx::demux_kernel<unsigned, 256>, 256, lds_bytes);
     return (int)e;
 }
 

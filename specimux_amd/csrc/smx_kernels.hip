@@ -251,10 +251,11 @@ __device__ __forceinline__ void bitsliced_shw(const unsigned *re, int MBW, const
         const unsigned code = c < ncol ? (unsigned)cw[c] : 15u;   // past the window: code 15 matches nothing
         const unsigned *rc = re + code * MBW;
         const int rlo = c - kidx, rhi = (c + kidx < m - 1) ? c + kidx : m - 1;   // in-band rows of this column
+        const unsigned rows = (rhi >= 0 ? (2u << rhi) - 1u : 0u) & (rlo > 0 ? ~0u << rlo : ~0u);   // one scalar test per row
         unsigned Ph = ~0u, Mh = 0u, Zb = 0u;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            if (i >= rlo && i <= rhi) {
+            if ((rows >> i) & 1u) {
                 const unsigned Eq = rc[i * rs];
                 const unsigned Z = Eq | Mh | Mv[i];
                 const unsigned nPh = Mv[i] | ~(Z | Pv[i]);

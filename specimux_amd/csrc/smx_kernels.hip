@@ -888,12 +888,15 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                         bool lt = score < best;
                         best = lt ? score : best;
                         jstar = lt ? j : jstar;
-                        cnt = lt ? 0 : cnt;
-                        bool eqb = score == best;
-                        cnt += eqb ? 1 : 0;
-                        word |= (eqb ? 1u : 0u) << (j & 31);
+                        word |= (score == best ? 1u : 0u) << (j & 31);
                     }
                     mrow[w] = word;
+                }
+                // number of optimal ends = bits at or after the first occurrence of the final minimum
+                for (int w = jstar >> 5; w < MW; w++) {
+                    unsigned word = mrow[w];
+                    if (w == (jstar >> 5)) word &= ~0u << (jstar & 31);
+                    cnt += __popc(word);
                 }
             } else {
                 for (int w = 0; w < MW; w++) {

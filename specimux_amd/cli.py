@@ -13,34 +13,49 @@ def version() -> str:
     return f"specimux version {__version__} (specimux_amd, MI355X)"
 
 
+# The reference's flag surface (src/specimux/cli.py:19-44), kept verbatim so that existing command lines and
+# `--help` output carry over: (flags, argparse keyword arguments).
+_POSITIONALS = [
+    ("primer_file", "Fasta file containing primer information"),
+    ("specimen_file", "TSV file containing specimen mapping with barcodes and primers"),
+    ("sequence_file", "Sequence file in Fasta or Fastq format, gzipped or plain text"),
+]
+_INT, _FLAG = dict(type=int), dict(action="store_true")
+_OPTIONS = [
+    (("--min-length",), dict(_INT, default=-1, help="Minimum sequence length.  Shorter sequences will be skipped (default: no filtering)")),
+    (("--max-length",), dict(_INT, default=-1, help="Maximum sequence length.  Longer sequences will be skipped (default: no filtering)")),
+    (("-n", "--num-seqs"), dict(type=str, default="-1", help="Number of sequences to read from file (e.g., -n 100 or -n 102,3)")),
+    (("-e", "--index-edit-distance"), dict(_INT, default=-1, help="Barcode edit distance value, default is half of min distance between barcodes")),
+    (("-E", "--primer-edit-distance"), dict(_INT, default=-1, help="Primer edit distance value, default is min distance between primers")),
+    (("-l", "--search-len"), dict(_INT, default=80, help="Length to search for index and primer at start and end of sequence (default: 80)")),
+    (("-F", "--output-to-files"), dict(_FLAG, help="Create individual sample files for sequences")),
+    (("-P", "--output-file-prefix"), dict(default="", help="Prefix for individual files when using -F (default: no prefix)")),
+    (("-O", "--output-dir"), dict(default=".", help="Directory for individual files when using -F (default: .)")),
+    (("--color",), dict(_FLAG, help="Highlight barcode matches in blue, primer matches in green")),
+    (("--trim",), dict(choices=[TrimMode.NONE, TrimMode.TAILS, TrimMode.BARCODES, TrimMode.PRIMERS], default=TrimMode.BARCODES,
+                       help="trimming to apply")),
+    (("--dereplicate",), dict(choices=[MultipleMatchStrategy.NONE, MultipleMatchStrategy.BEST], default=MultipleMatchStrategy.BEST,
+                              help="Dereplication strategy: 'best' selects best match per specimen/barcode group (default), "
+                                   "'none' outputs all matches")),
+    (("-d", "--diagnostics"), dict(_INT, nargs="?", const=1, choices=[1, 2, 3],
+                                   help="Enable diagnostic trace logging: 1=standard (default), 2=detailed, 3=verbose")),
+    (("-D", "--debug"), dict(_FLAG, help="Enable debug logging")),
+    (("--disable-prefilter",), dict(_FLAG, help="Disable barcode prefiltering (bloom filter optimization)")),
+    (("--disable-preorient",), dict(_FLAG, help="Disable heuristic pre-orientation")),
+    (("-t", "--threads"), dict(_INT, default=-1, help="Number of worker threads to use")),
+    (("--sample-topq",), dict(_INT, default=0, metavar="N",
+                              help="Create subsample directories with top N sequences by average quality score (default: disabled)")),
+]
+
+
 def build_parser() -> argparse.ArgumentParser:
-    p = argparse.ArgumentParser(description="Specimux: Demultiplex MinION sequences by dual barcode indexes and primers.")
-    p.add_argument("primer_file", help="Fasta file containing primer information")
-    p.add_argument("specimen_file", help="TSV file containing specimen mapping with barcodes and primers")
-    p.add_argument("sequence_file", help="Sequence file in Fasta or Fastq format, gzipped or plain text")
-    p.add_argument("--min-length", type=int, default=-1, help="Minimum sequence length.  Shorter sequences will be skipped (default: no filtering)")
-    p.add_argument("--max-length", type=int, default=-1, help="Maximum sequence length.  Longer sequences will be skipped (default: no filtering)")
-    p.add_argument("-n", "--num-seqs", type=str, default="-1", help="Number of sequences to read from file (e.g., -n 100 or -n 102,3)")
-    p.add_argument("-e", "--index-edit-distance", type=int, default=-1, help="Barcode edit distance value, default is half of min distance between barcodes")
-    p.add_argument("-E", "--primer-edit-distance", type=int, default=-1, help="Primer edit distance value, default is min distance between primers")
-    p.add_argument("-l", "--search-len", type=int, default=80, help="Length to search for index and primer at start and end of sequence (default: 80)")
-    p.add_argument("-F", "--output-to-files", action="store_true", help="Create individual sample files for sequences")
-    p.add_argument("-P", "--output-file-prefix", default="", help="Prefix for individual files when using -F (default: no prefix)")
-    p.add_argument("-O", "--output-dir", default=".", help="Directory for individual files when using -F (default: .)")
-    p.add_argument("--color", action="store_true", help="Highlight barcode matches in blue, primer matches in green")
-    p.add_argument("--trim", choices=[TrimMode.NONE, TrimMode.TAILS, TrimMode.BARCODES, TrimMode.PRIMERS], default=TrimMode.BARCODES, help="trimming to apply")
-    p.add_argument("--dereplicate", choices=[MultipleMatchStrategy.NONE, MultipleMatchStrategy.BEST], default=MultipleMatchStrategy.BEST,
-                   help="Dereplication strategy: 'best' selects best match per specimen/barcode group (default), 'none' outputs all matches")
-    p.add_argument("-d", "--diagnostics", nargs="?", const=1, type=int, choices=[1, 2, 3],
-                   help="Enable diagnostic trace logging: 1=standard (default), 2=detailed, 3=verbose")
-    p.add_argument("-D", "--debug", action="store_true", help="Enable debug logging")
-    p.add_argument("--disable-prefilter", action="store_true", help="Disable barcode prefiltering (bloom filter optimization)")
-    p.add_argument("--disable-preorient", action="store_true", help="Disable heuristic pre-orientation")
-    p.add_argument("-t", "--threads", type=int, default=-1, help="Number of worker threads to use")
-    p.add_argument("--sample-topq", type=int, default=0, metavar="N",
-                   help="Create subsample directories with top N sequences by average quality score (default: disabled)")
-    p.add_argument("-v", "--version", action="version", version=version())
-    return p
+    parser = argparse.ArgumentParser(description="Specimux: Demultiplex MinION sequences by dual barcode indexes and primers.")
+    for name, text in _POSITIONALS:
+        parser.add_argument(name, help=text)
+    for flags, kwargs in _OPTIONS:
+        parser.add_argument(*flags, **kwargs)
+    parser.add_argument("-v", "--version", action="version", version=version())
+    return parser
 
 
 def parse_args(argv):

@@ -296,6 +296,77 @@ __device__ __forceinline__ void bitsliced_shw(const unsigned *re, int MBW, const
     }
 }
 
+// Same banded DP with a fixed band half-width KB >= k and the 2*KB+1 live rows kept in a circular register
+// window (row r lives in slot r mod WIN).  The column loop is unrolled by WIN so every slot index is static:
+// 14 state registers for KB = 3 instead of 32.  A wider band than k is still exact (it contains the k band).
+template <int KB>
+__device__ __forceinline__ void bitsliced_shw_win(const unsigned *re, int MBW, const unsigned char *cw, int ncol, int m,
+                                                  int kidx, unsigned (&seen)[KB + 1]) {
+    constexpr int WIN = 2 * KB + 1;
+    unsigned Pw[WIN], Mw[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; i++) { Pw[i] = ~0u; Mw[i] = 0u; }
+    const int b0 = KB < m ? KB : m;   // D(bottom in-band row of column 0)
+    unsigned s0 = (b0 & 1) ? ~0u : 0u, s1 = (b0 & 2) ? ~0u : 0u, s2 = (b0 & 4) ? ~0u : 0u, s3 = (b0 & 8) ? ~0u : 0u,
+             s4 = (b0 & 16) ? ~0u : 0u;
+#pragma unroll
+    for (int d = 0; d <= KB; d++) seen[d] = 0u;
+    const int ncols = m + kidx, rs = 16 * MBW;
+    for (int c0 = 0; c0 < ncols; c0 += WIN) {
+#pragma unroll
+        for (int u = 0; u < WIN; u++) {
+            const int c = c0 + u;
+            if (c < ncols) {
+                const unsigned code = c < ncol ? (unsigned)cw[c] : 15u;
+                const unsigned *rc = re + code * MBW;
+                // the row entering the band (c + KB) takes the slot of the row that left it: back to the initial delta
+                Pw[(u + KB) % WIN] = ~0u; Mw[(u + KB) % WIN] = 0u;
+                unsigned Ph = ~0u, Mh = 0u, Zb = 0u;
+#pragma unroll
+                for (int w = 0; w < WIN; w++) {
+                    const int row = c - KB + w;                // slot = row mod WIN = (u - KB + w) mod WIN, static
+                    const int sl = ((u - KB + w) % WIN + WIN) % WIN;
+                    if (row >= 0 && row < m) {
+                        const unsigned Eq = rc[row * rs];
+                        const unsigned Z = Eq | Mh | Mw[sl];
+                        const unsigned nPh = Mw[sl] | ~(Z | Pw[sl]);
+                        const unsigned nMh = Pw[sl] & Z;
+                        const unsigned nPv = Mh | ~(Z | Ph);
+                        const unsigned nMv = Ph & Z;
+                        Pw[sl] = nPv; Mw[sl] = nMv; Ph = nPh; Mh = nMh;
+                        Zb = Z;
+                    }
+                }
+                unsigned inc, dec;
+                if (c + KB <= m - 1) { inc = ~Zb; dec = 0u; }
+                else { inc = Ph; dec = Mh; }
+                {
+                    unsigned cy = inc, t;
+                    t = s0 & cy; s0 ^= cy; cy = t;
+                    t = s1 & cy; s1 ^= cy; cy = t;
+                    t = s2 & cy; s2 ^= cy; cy = t;
+                    t = s3 & cy; s3 ^= cy; cy = t;
+                    s4 ^= cy;
+                    unsigned bw = dec;
+                    t = ~s0 & bw; s0 ^= bw; bw = t;
+                    t = ~s1 & bw; s1 ^= bw; bw = t;
+                    t = ~s2 & bw; s2 ^= bw; bw = t;
+                    t = ~s3 & bw; s3 ^= bw; bw = t;
+                    s4 ^= bw;
+                }
+                if (c >= m - KB - 1) {   // the tracked cell sits on the last row from here on
+                    const unsigned live = c < ncol ? ~0u : 0u;
+                    const unsigned hi = ~(s4 | s3) & live;
+#pragma unroll
+                    for (int d = 0; d <= KB; d++)
+                        if (d <= kidx)
+                            seen[d] |= hi & ((d & 1) ? s0 : ~s0) & ((d & 2) ? s1 : ~s1) & ((d & 4) ? s2 : ~s2);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Scorer helpers (phase 4).  Everything is indexed, nothing is string keyed.
 // Small per-panel tables staged in LDS (the scorer and the barcode scan read them constantly).
@@ -1073,7 +1144,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     unsigned *dm = dmask + ((en.slot >> logG) * (kidx + 1)) * MBW + w;
                     if (kidx < 4) {
                         unsigned seen[4];
-                        bitsliced_shw<4>(bsre + p * T.BSP + w, MBW, cwt, en.ncol, bsm, kidx, seen);
+                        bitsliced_shw_win<3>(bsre + p * T.BSP + w, MBW, cwt, en.ncol, bsm, kidx, seen);
 #pragma unroll
                         for (int d = 0; d < 4; d++)
                             if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);

@@ -896,42 +896,71 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         for (int i = tid; i < nr * 2 * (MW + 1); i += NT) namask[i] = 0;
         __syncthreads();
         {
-            const int chunks = stride / 16;
-            const uint4 *src = (const uint4 *)(windows + (size_t)r0 * stride);
-            for (int ci = tid; ci < nr * chunks; ci += NT) {
-                int r = ci / chunks, cpos = (ci - r * chunks) * 16;
-                uint4 v = src[ci];
+            // one 16-byte chunk: generic per-byte encode (short reads, search_len not a multiple of 16)
+            auto encode_bytes = [&](int r, int cpos, const uint4 &v) {
                 int L = lensL[r];
                 int Sp = L < S ? L : S;
                 unsigned w[4] = {v.x, v.y, v.z, v.w};
                 unsigned char *rowA = codes + (r * 2 + 0) * CS, *rowB = codes + (r * 2 + 1) * CS;
-                unsigned nam = 0;   // bit b: byte b of this chunk is a live non-ACGT base
-#pragma unroll
                 for (int b = 0; b < 16; b++) {
                     int pos = cpos + b;
                     unsigned ch = (w[b >> 2] >> ((b & 3) * 8)) & 0xFF;
                     if (pos < S) {            // head byte i -> A[Sp-1-i] = code(complement)
                         if (pos < Sp) {
                             unsigned cd = lut[256 + ch];
-                            rowA[Sp - 1 - pos] = (unsigned char)cd;
-                            nam |= (cd > 3 ? 1u : 0u) << b;
+                            int j = Sp - 1 - pos;
+                            rowA[j] = (unsigned char)cd;
+                            if (cd > 3) atomicOr(&namask[(r * 2 + 0) * (MW + 1) + (j >> 5)], 1u << (j & 31));
                         }
                     } else if (pos < 2 * S) { // tail byte j -> B[j]
                         int j = pos - S;
                         if (j < Sp) {
                             unsigned cd = lut[ch];
                             rowB[j] = (unsigned char)cd;
-                            nam |= (cd > 3 ? 1u : 0u) << b;
+                            if (cd > 3) atomicOr(&namask[(r * 2 + 1) * (MW + 1) + (j >> 5)], 1u << (j & 31));
                         }
                     }
                 }
-                if (nam) {   // rare: scatter the flags into the per-row bitmasks used by the prefilter rule
-                    for (int b = 0; b < 16; b++) {
-                        if (!((nam >> b) & 1)) continue;
-                        int pos = cpos + b;
-                        int row = pos < S ? 0 : 1, j = pos < S ? Sp - 1 - pos : pos - S;
-                        atomicOr(&namask[(r * 2 + row) * (MW + 1) + (j >> 5)], 1u << (j & 31));
+            };
+            if ((S & 15) == 0) {
+                // fast path: chunks never straddle the head/tail boundary; items are ordered [all head chunks]
+                // [all tail chunks] so that a wave is (almost always) uniform in role.  Full windows (len >= S):
+                // four LUT lookups -> one packed dword store; the head is written reversed (reverse complement).
+                const int hc = S >> 4, nhead = nr * hc, S4 = S >> 2;
+                for (int ci = tid; ci < 2 * nhead; ci += NT) {
+                    const bool tail = ci >= nhead;
+                    const int k = tail ? ci - nhead : ci;
+                    const int r = k / hc, c = k - r * hc;
+                    const uint4 v = *(const uint4 *)(windows + (size_t)(r0 + r) * stride + (tail ? S : 0) + 16 * c);
+                    if (lensL[r] >= S) {
+                        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                        const unsigned char *lt = lut + (tail ? 0 : 256);
+                        unsigned *dst = (unsigned *)(codes + (r * 2 + (tail ? 1 : 0)) * CS);
+                        unsigned any = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            unsigned c0 = lt[w[q] & 0xFF], c1 = lt[(w[q] >> 8) & 0xFF], c2 = lt[(w[q] >> 16) & 0xFF], c3 = lt[w[q] >> 24];
+                            unsigned packed = tail ? (c0 | (c1 << 8) | (c2 << 16) | (c3 << 24))
+                                                   : (c3 | (c2 << 8) | (c1 << 16) | (c0 << 24));
+                            dst[tail ? 4 * c + q : S4 - 1 - (4 * c + q)] = packed;
+                            any |= packed;
+                        }
+                        if (any & 0x0C0C0C0Cu) {   // rare: a non-ACGT base in this chunk -> flag it for the prefilter rule
+                            const unsigned char *row = (const unsigned char *)dst;
+                            const int j0 = tail ? 16 * c : S - 16 * c - 16;
+                            for (int j = j0; j < j0 + 16; j++)
+                                if (row[j] > 3) atomicOr(&namask[(r * 2 + (tail ? 1 : 0)) * (MW + 1) + (j >> 5)], 1u << (j & 31));
+                        }
+                    } else {
+                        encode_bytes(r, (tail ? S : 0) + 16 * c, v);
                     }
+                }
+            } else {
+                const int chunks = stride / 16;
+                const uint4 *src = (const uint4 *)(windows + (size_t)r0 * stride);
+                for (int ci = tid; ci < nr * chunks; ci += NT) {
+                    int r = ci / chunks;
+                    encode_bytes(r, (ci - r * chunks) * 16, src[ci]);
                 }
             }
         }

@@ -44,6 +44,21 @@ __device__ __forceinline__ void myers_step(W Eq, W &Pv, W &Mv, int &score, int t
     Mv = Ph & Xv;
 }
 
+// HW column step for a 32-bit pattern LEFT-ALIGNED in its word (row m-1 = bit 31; the padding rows below the
+// pattern have Eq = 0 and stay inert: Pv = 1, Mv = Ph = Mh = 0), so the score delta is two plain shifts of
+// the top bit (one of them arithmetic: -1) and a three-operand add.
+__device__ __forceinline__ void myers_step_hw_top(unsigned Eq, unsigned &Pv, unsigned &Mv, int &score) {
+    unsigned Xv = Eq | Mv;
+    unsigned Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    unsigned Ph = Mv | ~(Xh | Pv);
+    unsigned Mh = Pv & Xh;
+    score = score + (int)(Ph >> 31) + ((int)Mh >> 31);
+    Ph <<= 1;
+    Mh <<= 1;
+    Pv = Mh | ~(Xv | Ph);
+    Mv = Ph & Xv;
+}
+
 // Geometry of one end string q of length L.  The stored window holds
 // q[L-Sp : L], Sp = min(S, L); window coordinate j <-> q index j + base.
 struct EndGeom {
@@ -833,12 +848,13 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     smx_op *opsL = (smx_op *)(lds + T.opsL);
     int *aggr = (int *)(lds + T.aggr);      // [0..7] counters, [8] round end rank
     const int tid = threadIdx.x, wave = tid >> 6;
+    constexpr int PWBITS = (int)sizeof(PW) * 8;
     const int CS = T.CS, NPs = T.NPs, NBs = T.NBs, lNPs = T.lNPs, lNBs = T.lNBs, G = T.G, logG = T.logG, MBW = T.MBW;
 
     // ---- phase 0: stage the panel (transposed: consecutive lanes = consecutive patterns hit distinct banks)
     for (int i = tid; i < NP * 16; i += NT) {
         int p = i >> 4, c = i & 15;
-        ppeq[c * NPs + p] = (PW)P->ppeq[i];
+        ppeq[c * NPs + p] = (PW)P->ppeq[i] << (PWBITS - P->pm[p]);   // left-aligned: row m-1 is the top bit
         if (P->need_starts) prpeq[c * NPs + p] = (PW)P->prpeq[i];
     }
     if (!use_bs)
@@ -974,11 +990,55 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             EndGeom g = end_geom(L, S);
             const unsigned char *cw = codes + (r * 2 + X) * CS;
             const PW *peq = ppeq + p;
-            const int m = LP.pm[p], k = LP.pk[p], top = m - 1;
+            const int m = LP.pm[p], k = LP.pk[p], top = PWBITS - 1;
             PW Pvv = ~(PW)0, Mv = 0;
             int score = m, best = m + 1, jstar = 0, cnt = 0;
             unsigned *mrow = masks + (size_t)item * MW;
-            if (g.j_lo == 0) {
+            if (sizeof(PW) == 4 && g.j_lo == 0 && (g.Sp & 3) == 0 && g.Sp > 0) {
+                // common case, 32-bit patterns: four columns per group, the next group's Eq words are fetched
+                // before the current group is computed (the compiler otherwise waits on every LDS read), and the
+                // "new minimum" / "equals minimum" flags are shifted into bit-reversed words via the carry flag
+                const int Sp = g.Sp;
+                const unsigned *cw4 = (const unsigned *)cw;
+                const unsigned *pq = (const unsigned *)ppeq + p;
+                unsigned Pu = ~0u, Mu = 0;
+                int sc = m, bst = m + 1;
+                unsigned cd = cw4[0];
+                unsigned e0 = pq[(cd & 0xFF) << lNPs], e1 = pq[((cd >> 8) & 0xFF) << lNPs],
+                         e2 = pq[((cd >> 16) & 0xFF) << lNPs], e3 = pq[(cd >> 24) << lNPs];
+                const int last4 = (Sp >> 2) - 1;
+                for (int w = 0; w < MW; w++) {
+                    const int ncols = Sp - w * 32 < 32 ? Sp - w * 32 : 32;
+                    // ltw: "new minimum" flags, gtw: "above the minimum" flags; the newest column is bit 0.  Both
+                    // are sign bits of a difference funnel-shifted in (v_alignbit): no compare, no select.
+                    unsigned gtw = 0, ltw = 0;
+                    for (int gi = 0; gi < (ncols >> 2); gi++) {
+                        int nx = w * 8 + gi + 1;
+                        cd = cw4[nx < last4 ? nx : last4];
+                        unsigned n0 = pq[(cd & 0xFF) << lNPs], n1 = pq[((cd >> 8) & 0xFF) << lNPs],
+                                 n2 = pq[((cd >> 16) & 0xFF) << lNPs], n3 = pq[(cd >> 24) << lNPs];
+#define SMX_PCOL(E) do { myers_step_hw_top(E, Pu, Mu, sc);                                             \
+                         ltw = __builtin_amdgcn_alignbit(ltw, (unsigned)(sc - bst), 31);                \
+                         gtw = __builtin_amdgcn_alignbit(gtw, (unsigned)(bst - sc), 31);                \
+                         bst = sc < bst ? sc : bst; } while (0)
+                        SMX_PCOL(e0); SMX_PCOL(e1); SMX_PCOL(e2); SMX_PCOL(e3);
+#undef SMX_PCOL
+                        e0 = n0; e1 = n1; e2 = n2; e3 = n3;
+                    }
+                    // column c of this word sits at bit ncols-1-c
+                    if (ncols > 0) {
+                        mrow[w] = __brev(~gtw) >> (32 - ncols);
+                        if (ltw) jstar = w * 32 + ncols - __ffs(ltw);
+                    } else mrow[w] = 0;
+                }
+                best = bst; score = sc;
+                Pvv = (PW)Pu; Mv = (PW)Mu;
+                for (int w = jstar >> 5; w < MW; w++) {
+                    unsigned word = mrow[w];
+                    if (w == (jstar >> 5)) word &= ~0u << (jstar & 31);
+                    cnt += __popc(word);
+                }
+            } else if (g.j_lo == 0) {
                 // common case: the target is the whole stored window; branch-free bookkeeping per column
                 const int Sp = g.Sp;
                 for (int w = 0; w < MW; w++) {
@@ -1036,7 +1096,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 for (int c = 1; c <= maxc; c++) {
                     int j = jstar - (c - 1);
                     if (j < g.j_lo) break;
-                    myers_step<PW, true>(rpeq[(int)cw[j] << lNPs], P2, M2, sc, top);
+                    myers_step<PW, true>(rpeq[(int)cw[j] << lNPs], P2, M2, sc, m - 1);   // rpeq is right-aligned
                     if (sc == best) lastc = c;
                 }
                 fs_j = jstar - (lastc - 1);

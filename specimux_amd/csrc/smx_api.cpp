@@ -387,7 +387,14 @@ static int ensure_device(smx_panel *P) {
         int rc = smx_set_demux_lds_limit(P->use64, std::max(P->lds, P->lds_slots));
         if (rc != 0) return fail(SMX_ERR_DEVICE, "cannot raise the dynamic LDS limit to %zu bytes", std::max(P->lds, P->lds_slots));
     }
-    P->blocks_per_cu = 8;   // persistent grid; tiles are pulled from a queue, so over-subscription is harmless
+    // persistent grid = exactly the resident workgroups (tiles are pulled from a queue): a workgroup that starts
+    // after the queue has drained would only pay the panel staging and its one-time register spills
+    {
+        int occ = 0;
+        size_t worst = std::max(P->lds, P->lds_slots);
+        if (smx_query_occupancy(P->use64, worst, &occ) != 0 || occ < 1) occ = 4;
+        P->blocks_per_cu = occ;
+    }
     if (const char *e = getenv("SMX_BLOCKS_PER_CU")) P->blocks_per_cu = std::max(1, atoi(e));
     if (getenv("SMX_DEBUG")) {
         int occ = -1;

@@ -847,7 +847,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     unsigned *emitlog = (unsigned *)(lds + T.emit);
     smx_op *opsL = (smx_op *)(lds + T.opsL);
     int *aggr = (int *)(lds + T.aggr);      // [0..7] counters, [8] round end rank
-    const int tid = threadIdx.x, wave = tid >> 6;
+    int tid = threadIdx.x;
+    const int wave = tid >> 6;
     constexpr int PWBITS = (int)sizeof(PW) * 8;
     const int CS = T.CS, NPs = T.NPs, NBs = T.NBs, lNPs = T.lNPs, lNBs = T.lNBs, G = T.G, logG = T.logG, MBW = T.MBW;
 
@@ -898,6 +899,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     // dynamic tile queue: workgroups pull tiles from a global counter (zeroed on the stream before the
     // launch), so the tail is one tile long whatever the residency turns out to be
     for (;;) {
+        // keep per-thread address arithmetic inside the tile body: hoisted out of this loop it lives in VGPRs across
+        // every phase and ends up spilled to scratch (HBM traffic, reload latency); recomputing it is a few ALU ops
+        asm volatile("" : "+v"(tid));
         if (tid == 0) aggr[9] = (int)atomicAdd(tile_counter, 1u);
         __syncthreads();
         const uint32_t tile = (uint32_t)aggr[9];

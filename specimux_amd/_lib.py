@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmx.so")
+LIB_PATH = os.environ.get("SMX_LIB") or os.path.join(_HERE, "libsmx.so")   # SMX_LIB: A/B builds (tools/tune.sh)
 
 ABI_VERSION = 1
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_DEVICE, ERR_OVERFLOW = 0, -1, -2, -3, -4

@@ -352,17 +352,17 @@ __device__ __forceinline__ void bitsliced_shw_win(const unsigned *re, int MBW, c
                         Zb = Z;
                     }
                 }
-                unsigned inc, dec;
-                if (c + KB <= m - 1) { inc = ~Zb; dec = 0u; }
-                else { inc = Ph; dec = Mh; }
+                const bool descending = c + KB <= m - 1;   // uniform: the bottom edge has not reached the last row yet
                 {
-                    unsigned cy = inc, t;
+                    unsigned cy = descending ? ~Zb : Ph, t;
                     t = s0 & cy; s0 ^= cy; cy = t;
                     t = s1 & cy; s1 ^= cy; cy = t;
                     t = s2 & cy; s2 ^= cy; cy = t;
                     t = s3 & cy; s3 ^= cy; cy = t;
                     s4 ^= cy;
-                    unsigned bw = dec;
+                }
+                if (!descending) {   // only the last row can lose a unit
+                    unsigned bw = Mh, t;
                     t = ~s0 & bw; s0 ^= bw; bw = t;
                     t = ~s1 & bw; s1 ^= bw; bw = t;
                     t = ~s2 & bw; s2 ^= bw; bw = t;
@@ -455,6 +455,9 @@ __device__ inline bool tied_has_global(const ReadCtx &c, int h, int gb) {
 
 // Specimens.specimen_for_exact_match (databases.py:232-245): first specimen in file order.
 __device__ inline int specimen_exact(const DevPanel *P, int gb1, int gb2, int f, int r) {
+#if defined(SMX_EXP) && (SMX_EXP == 1 || SMX_EXP == 4)
+    return (gb1 + gb2) % P->NS;   // timing experiment only: no pointer chase
+#endif
     for (int s = P->pairhead[gb1 * P->NB + gb2]; s >= 0; s = P->spec_next[s])
         if (((P->spec_p1m[s] >> f) & 1) && ((P->spec_p2m[s] >> r) & 1)) return s;
     return -1;
@@ -554,8 +557,12 @@ __device__ inline void emit_op(Emitter &E, const CandView *v, int cand_id, int s
     if (rtype == SMX_R_FULL || rtype == SMX_R_DEREP_FULL) E.matched = true;
     // counters
     int cls = (op.rtype == SMX_R_UNKNOWN) ? 2 : ((op.rtype == SMX_R_PARTIAL_FWD || op.rtype == SMX_R_PARTIAL_REV) ? 1 : 0);
+#if !(defined(SMX_EXP) && (SMX_EXP == 3 || SMX_EXP == 4))
     atomicAdd(&E.aggr[3 + cls], 1);
+#endif
+#if !(defined(SMX_EXP) && (SMX_EXP == 2 || SMX_EXP == 4))
     if (cls == 0 && op.sample >= 0) atomicAdd(&E.counts[SMX_CNT_SPECIMEN0 + op.sample], 1ull);
+#endif
     if (E.n == 0) {
         *E.primary = op;
     } else {
@@ -635,53 +642,50 @@ __device__ inline bool score_fast(Emitter &E, int ori) {
             if (sc > best) { best = sc; nbest = 1; only_pair = pair; only_o = o; }
             else if (sc == best) nbest++;
         }
+    // The divergent case analysis below only picks the parameters of the ONE record this read emits; the record
+    // itself is built once, after the lanes have converged again (emit_op is by far the longest piece of code here).
+    bool has_v = true;
+    int pair = only_pair, o = only_o, sample = -1, rtype = SMX_R_UNKNOWN, barcode = -1, pool = -2;   // pool -2: the pair's
+    unsigned xflags = 0;
     if (best == 0) {   // no candidate at all (demultiplex.py:202-210)
-        emit_op(E, nullptr, 0, -1, SMX_R_UNKNOWN, -1, -1, 0);
-        return true;
-    }
-    if (best <= 2 && nbest > 1) {
+        has_v = false; pair = 0; o = 0; pool = -1;
+    } else if (best <= 2 && nbest > 1) {
         // several primer-only candidates (typically both orientations of one pair): no barcode logic involved.
         // dereplicate=best -> dereplicate_unknown_matches: stable minimum of (-primer_count, primer_dist, file index);
-        // dereplicate=none -> every best candidate is written as UNKNOWN (demultiplex.py:181-197, :480-538)
-        int wkey = 0x7FFFFFFF, wpair = 0, wo = 0;
-        for (int pair = 0; pair < P->NPAIR; pair++)
-            for (int o = 0; o < 2; o++) {
-                if ((o == 0 && ori == 2) || (o == 1 && ori == 1)) continue;
-                CandView v = cand_view(c, pair, o);
+        // dereplicate=none -> every best candidate is written as UNKNOWN (demultiplex.py:181-197, :480-538): general path
+        if (P->derep == SMX_DEREP_NONE) return false;
+        int wkey = 0x7FFFFFFF;
+        for (int pr = 0; pr < P->NPAIR; pr++)
+            for (int oo = 0; oo < 2; oo++) {
+                if ((oo == 0 && ori == 2) || (oo == 1 && ori == 1)) continue;
+                CandView v = cand_view(c, pr, oo);
                 if (cand_score(v) != best) continue;
-                if (P->derep == SMX_DEREP_NONE) {
-                    emit_op(E, &v, pair * 2 + o, -1, SMX_R_UNKNOWN, c.LP.pair_pool[pair], -1, 0);
-                } else {
-                    int k = key_unknown(c.LP, v);
-                    if (k < wkey) { wkey = k; wpair = pair; wo = o; }
-                }
+                int k = key_unknown(c.LP, v);
+                if (k < wkey) { wkey = k; pair = pr; o = oo; }
             }
-        if (P->derep != SMX_DEREP_NONE) {
-            CandView w = cand_view(c, wpair, wo);
-            emit_op(E, &w, wpair * 2 + wo, -1, SMX_R_UNKNOWN, c.LP.pair_pool[wpair], -1, 0);
+    } else {
+        if (nbest != 1) return false;
+        const CandView v = cand_view(c, pair, o);
+        const HitL &a = c.hits[v.h1], &b = c.hits[v.h2];
+        const bool t1 = !v.b1 || a.ntied == 1, t2 = !v.b2 || b.ntied == 1;
+        if (best <= 2) {
+            // dereplicate_unknown_matches / resolve_specimen: UNKNOWN either way
+        } else if (!(t1 && t2)) {
+            return false;
+        } else if (best <= 4) {   // one (direction, barcode) group: resolve_specimen (demultiplex.py:576-589)
+            if (v.b1 && !v.b2) { rtype = SMX_R_PARTIAL_FWD; barcode = global_bc(c, v.h1, a.first_tied); }
+            else if (v.b2 && !v.b1) { rtype = SMX_R_PARTIAL_REV; barcode = global_bc(c, v.h2, b.first_tied); }
+        } else {
+            if (P->derep != SMX_DEREP_BEST) return false;
+            int spec = specimen_exact(P, global_bc(c, v.h1, a.first_tied), global_bc(c, v.h2, b.first_tied), v.f, v.r);
+            if (spec >= 0) { sample = spec; rtype = SMX_R_DEREP_FULL; pool = P->spec_pool[spec]; }
+            else xflags = SMX_OPF_NO_SPECIMEN;
         }
-        return true;
     }
-    if (nbest != 1) return false;
-    CandView v = cand_view(c, only_pair, only_o);
-    int cand_id = only_pair * 2 + only_o, cand_pool = c.LP.pair_pool[only_pair];
-    bool t1 = !v.b1 || c.hits[v.h1].ntied == 1, t2 = !v.b2 || c.hits[v.h2].ntied == 1;
-    if (best <= 2) {   // dereplicate_unknown_matches / resolve_specimen: UNKNOWN either way
-        emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, cand_pool, -1, 0);
-        return true;
-    }
-    if (best <= 4 && t1 && t2) {   // one (direction, barcode) group
-        emit_partial_or_unknown(E, v, cand_id, cand_pool);
-        return true;
-    }
-    if (best == 5 && t1 && t2 && P->derep == SMX_DEREP_BEST) {
-        int spec = specimen_exact(P, global_bc(c, v.h1, c.hits[v.h1].first_tied),
-                                  global_bc(c, v.h2, c.hits[v.h2].first_tied), v.f, v.r);
-        if (spec >= 0) emit_op(E, &v, cand_id, spec, SMX_R_DEREP_FULL, P->spec_pool[spec], -1, 0);
-        else emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, cand_pool, -1, SMX_OPF_NO_SPECIMEN);
-        return true;
-    }
-    return false;
+    if (pool == -2) pool = c.LP.pair_pool[pair];
+    const CandView v = cand_view(c, pair, o);
+    emit_op(E, has_v ? &v : nullptr, pair * 2 + o, sample, rtype, pool, barcode, xflags);
+    return true;
 }
 
 // General scorer (deferred kernel only): the reference's selection / dereplication in full.
@@ -1397,7 +1401,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             if (r < nr) {
                 int L = lensL[r];
                 bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
+#if !(defined(SMX_EXP) && (SMX_EXP == 3 || SMX_EXP == 4))
                 atomicAdd(&aggr[0], 1);
+#endif
                 if (filtered) {
                     atomicAdd(&aggr[2], 1);
                     smx_op op;
@@ -1418,7 +1424,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     E.n = 0; E.matched = false; E.overflow = false;
                     if (score_fast(E, ori)) {
                         opsL[r].n_ops = (uint16_t)E.n;
+#if !(defined(SMX_EXP) && (SMX_EXP == 3 || SMX_EXP == 4))
                         if (E.matched) atomicAdd(&aggr[1], 1);
+#endif
                         if (E.n > 1) atomicAdd(&aggr[6], 1);
                         if (E.overflow) atomicAdd(&aggr[7], 1);
                     } else if (!SMX_DEFER) {

@@ -11,6 +11,7 @@ for cfg in "$@"; do
       T=*) env_args="$env_args SMX_PHASE_TIMING=1";;
       P=*) env_args="$env_args SMX_LDS_PAD=${kv#P=}";;
       D=*) env_args="$env_args SMX_DEBUG=1";;
+      X=*) env_args="$env_args SMX_LIB=$GRAFT_REPO_ROOT/build_exp/libsmx_${kv#X=}.so";;
     esac
   done
   out=$(env $env_args python bench.py --no-cpu-baseline --steps 10 --warmup 2 2>gpurun_out/tune.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.1f Mreads/s kernel %.3f ms' % (d['value']/1e6, d['roofline']['kernel_ms_avg']))")

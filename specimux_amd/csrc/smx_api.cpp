@@ -321,6 +321,17 @@ void smx_panel_destroy(smx_panel *P) {
             fprintf(stderr, "[smx phase timing] R=%d lds=%zu blocks/CU=%d:", P->R, P->lds, P->blocks_per_cu);
             for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.1f%%", names[i], tot ? 100.0 * sum[i] / tot : 0.0);
             fprintf(stderr, "\n");
+            if (getenv("SMX_DEBUG")) {   // where did wave w of each workgroup land?  hist[w][simd]
+                int hist[4][4] = {{0}};
+                for (int b = 0; b < P->phase_grid; b++)
+                    for (int w = 0; w < 4; w++) hist[w][(h[(size_t)b * 16 + 10 + w] >> 4) & 3]++;
+                for (int w = 0; w < 4; w++)
+                    fprintf(stderr, "[smx placement] wave %d on simd 0..3: %d %d %d %d\n", w, hist[w][0], hist[w][1], hist[w][2], hist[w][3]);
+                for (int b = 0; b < 12 && b < P->phase_grid; b++) {
+                    unsigned v = (unsigned)h[(size_t)b * 16 + 10];
+                    fprintf(stderr, "[smx placement] block %d wave0: slot %u simd %u cu %u sh %u se %u\n", b, v & 15, (v >> 4) & 3, (v >> 8) & 15, (v >> 12) & 1, (v >> 13) & 7);
+                }
+            }
         }
         (void)hipFree(P->d_phase);
     }

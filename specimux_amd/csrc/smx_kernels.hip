@@ -1484,6 +1484,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     }
     if (timing)
         for (int i = 0; i < 10; i++) P->dbg_phase[(size_t)blockIdx.x * 16 + i] += tacc[i];
+    if (P->dbg_phase != nullptr && (tid & 63) == 0)   // placement of this wave: HW_ID (simd, wave slot, cu, se)
+        P->dbg_phase[(size_t)blockIdx.x * 16 + 10 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
 #undef STAMP
     // block aggregates -> global counters
     if (tid < 8 && aggr[tid]) atomicAdd(&counts[tid], (unsigned long long)aggr[tid]);

@@ -15,5 +15,5 @@ for cfg in "$@"; do
     esac
   done
   out=$(env $env_args python bench.py --no-cpu-baseline --steps 10 --warmup 2 2>gpurun_out/tune.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.1f Mreads/s kernel %.3f ms' % (d['value']/1e6, d['roofline']['kernel_ms_avg']))")
-  echo "[$cfg] $out $(grep -E 'phase timing|occupancy API' gpurun_out/tune.err | tail -2 | tr '\n' ' ')"
+  echo "[$cfg] $out $(grep -E "phase timing|occupancy API|placement" gpurun_out/tune.err | tail -20 | tr '\n' ' ')"
 done

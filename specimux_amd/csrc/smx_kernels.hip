@@ -180,8 +180,8 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     o = (o + 15) & ~15;
     t.codes = o; o += R * 2 * t.CS;
     t.namask = o; o += R * 2 * (MW + 1) * 4;   // per code row: bit j set = code[j] is not A/C/G/T (+1 guard word)
-    t.lens = o;  o += R * 4;
-    t.ocnt = o;  o += R * 2 * 4;
+    t.lens = o;  o += 2 * R * 4;               // double-buffered: the next tile is encoded while this one is scored
+    t.ocnt = o;  o += 2 * R * 2 * 4;
     t.hits = o;  o += R * H * (int)sizeof(HitL);
     t.masks = o; o += R * H * MW * 4;
     t.tiem = o;  o += R * H * t.MBW * 4;
@@ -902,99 +902,27 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 #define STAMP(i) do { if (timing) { unsigned long long _t = clock64(); tacc[i] += _t - tacc[10]; tacc[10] = _t; } } while (0)
     // dynamic tile queue: workgroups pull tiles from a global counter (zeroed on the stream before the
     // launch), so the tail is one tile long whatever the residency turns out to be
+    // Software pipeline over tiles: while the lowest wave(s) run the scorer of tile t (one lane per read), the other
+    // waves load and encode tile t+1.  codes / namask are dead by then; lens and the orientation votes are double-buffered.
+    const int SW = (R + 63) >> 6;              // scorer waves
+    uint32_t cur = 0xFFFFFFFFu;                // tile being processed (none yet)
+    int par = 1;                               // cur's lens/ocnt buffer; the tile being encoded uses par ^ 1
     for (;;) {
         // keep per-thread address arithmetic inside the tile body: hoisted out of this loop it lives in VGPRs across
         // every phase and ends up spilled to scratch (HBM traffic, reload latency); recomputing it is a few ALU ops
         asm volatile("" : "+v"(tid));
-        if (tid == 0) aggr[9] = (int)atomicAdd(tile_counter, 1u);
-        __syncthreads();
-        const uint32_t tile = (uint32_t)aggr[9];
-        if (tile >= n_tiles) break;
-        const uint32_t r0 = tile * R;
-        const int nr = (int)((n_reads - r0) < (uint32_t)R ? (n_reads - r0) : (uint32_t)R);
+        const bool have = cur != 0xFFFFFFFFu;
+        if (tid == 0) aggr[9] = (int)atomicAdd(tile_counter, 1u);   // the tile to encode during this iteration
+        const uint32_t r0 = have ? cur * R : 0u;
+        const int nr = have ? (int)((n_reads - r0) < (uint32_t)R ? (n_reads - r0) : (uint32_t)R) : 0;
         const int nh = nr * H;
+        int *lensC = lensL + par * R, *ocntC = ocnt + par * 2 * R;
         if (timing) tacc[10] = clock64();
-
-        // ---- phase 1: windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
-        if (tid < nr) { lensL[tid] = lens[r0 + tid]; ocnt[2 * tid] = 0; ocnt[2 * tid + 1] = 0; }
-        for (int i = tid; i < nr * 2 * (MW + 1); i += NT) namask[i] = 0;
-        __syncthreads();
-        {
-            // one 16-byte chunk: generic per-byte encode (short reads, search_len not a multiple of 16)
-            auto encode_bytes = [&](int r, int cpos, const uint4 &v) {
-                int L = lensL[r];
-                int Sp = L < S ? L : S;
-                unsigned w[4] = {v.x, v.y, v.z, v.w};
-                unsigned char *rowA = codes + (r * 2 + 0) * CS, *rowB = codes + (r * 2 + 1) * CS;
-                for (int b = 0; b < 16; b++) {
-                    int pos = cpos + b;
-                    unsigned ch = (w[b >> 2] >> ((b & 3) * 8)) & 0xFF;
-                    if (pos < S) {            // head byte i -> A[Sp-1-i] = code(complement)
-                        if (pos < Sp) {
-                            unsigned cd = lut[256 + ch];
-                            int j = Sp - 1 - pos;
-                            rowA[j] = (unsigned char)cd;
-                            if (cd > 3) atomicOr(&namask[(r * 2 + 0) * (MW + 1) + (j >> 5)], 1u << (j & 31));
-                        }
-                    } else if (pos < 2 * S) { // tail byte j -> B[j]
-                        int j = pos - S;
-                        if (j < Sp) {
-                            unsigned cd = lut[ch];
-                            rowB[j] = (unsigned char)cd;
-                            if (cd > 3) atomicOr(&namask[(r * 2 + 1) * (MW + 1) + (j >> 5)], 1u << (j & 31));
-                        }
-                    }
-                }
-            };
-            if ((S & 15) == 0) {
-                // fast path: chunks never straddle the head/tail boundary; items are ordered [all head chunks]
-                // [all tail chunks] so that a wave is (almost always) uniform in role.  Full windows (len >= S):
-                // four LUT lookups -> one packed dword store; the head is written reversed (reverse complement).
-                const int hc = S >> 4, nhead = nr * hc, S4 = S >> 2;
-                for (int ci = tid; ci < 2 * nhead; ci += NT) {
-                    const bool tail = ci >= nhead;
-                    const int k = tail ? ci - nhead : ci;
-                    const int r = k / hc, c = k - r * hc;
-                    const uint4 v = *(const uint4 *)(windows + (size_t)(r0 + r) * stride + (tail ? S : 0) + 16 * c);
-                    if (lensL[r] >= S) {
-                        const unsigned w[4] = {v.x, v.y, v.z, v.w};
-                        const unsigned char *lt = lut + (tail ? 0 : 256);
-                        unsigned *dst = (unsigned *)(codes + (r * 2 + (tail ? 1 : 0)) * CS);
-                        unsigned any = 0;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            unsigned c0 = lt[w[q] & 0xFF], c1 = lt[(w[q] >> 8) & 0xFF], c2 = lt[(w[q] >> 16) & 0xFF], c3 = lt[w[q] >> 24];
-                            unsigned packed = tail ? (c0 | (c1 << 8) | (c2 << 16) | (c3 << 24))
-                                                   : (c3 | (c2 << 8) | (c1 << 16) | (c0 << 24));
-                            dst[tail ? 4 * c + q : S4 - 1 - (4 * c + q)] = packed;
-                            any |= packed;
-                        }
-                        if (any & 0x0C0C0C0Cu) {   // rare: a non-ACGT base in this chunk -> flag it for the prefilter rule
-                            const unsigned char *row = (const unsigned char *)dst;
-                            const int j0 = tail ? 16 * c : S - 16 * c - 16;
-                            for (int j = j0; j < j0 + 16; j++)
-                                if (row[j] > 3) atomicOr(&namask[(r * 2 + (tail ? 1 : 0)) * (MW + 1) + (j >> 5)], 1u << (j & 31));
-                        }
-                    } else {
-                        encode_bytes(r, (tail ? S : 0) + 16 * c, v);
-                    }
-                }
-            } else {
-                const int chunks = stride / 16;
-                const uint4 *src = (const uint4 *)(windows + (size_t)r0 * stride);
-                for (int ci = tid; ci < nr * chunks; ci += NT) {
-                    int r = ci / chunks;
-                    encode_bytes(r, (ci - r * chunks) * 16, src[ci]);
-                }
-            }
-        }
-        __syncthreads();
-        STAMP(0);
-
+        if (have) {
         // ---- phase 2: primer scan, one lane per (read, primer, end)
         for (int item = tid; item < nh; item += NT) {
             int r = item / H, h = item - r * H, p = h >> 1, X = h & 1;
-            int L = lensL[r];
+            int L = lensC[r];
             EndGeom g = end_geom(L, S);
             const unsigned char *cw = codes + (r * 2 + X) * CS;
             const PW *peq = ppeq + p;
@@ -1121,7 +1049,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 // determine_orientation via A.6: fwd primer in A / rev primer in B vote "forward"
                 int dir = LP.pdir[p];
                 int vote_fwd = (dir == 0) ? (X == 0) : (X == 1);
-                atomicAdd(&ocnt[2 * r + (vote_fwd ? 0 : 1)], 1);
+                atomicAdd(&ocntC[2 * r + (vote_fwd ? 0 : 1)], 1);
             }
         }
         __syncthreads();
@@ -1130,8 +1058,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         // ---- phase 3a: orientation, which ends need barcodes; scans of locations (A) and searched hits (B)
         for (int item = tid; item < nh; item += NT) {
             int r = item / H, h = item - r * H, p = h >> 1, X = h & 1;
-            int L = lensL[r];
-            int f = ocnt[2 * r], rv = ocnt[2 * r + 1];
+            int L = lensC[r];
+            int f = ocntC[2 * r], rv = ocntC[2 * r + 1];
             int ori = 3;   // bit0: as-read candidates allowed, bit1: reverse-complement candidates allowed
             if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
             bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
@@ -1189,7 +1117,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 int item = queue[q];
                 int r = item / H, h = item - r * H, X = h & 1;
                 const HitL &hl = hits[item];
-                int L = lensL[r];
+                int L = lensC[r];
                 EndGeom g = end_geom(L, S);
                 const unsigned *mrow = masks + (size_t)item * MW;
                 const unsigned *na = namask + (r * 2 + X) * (MW + 1);
@@ -1322,7 +1250,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     unsigned v = live ? bres[i] : 0xFFFFFFFFu;
                     if (live && dbg_bdist)
                         dbg_bdist[(size_t)r0 * H * maxB + (size_t)item * maxB + sl] = (v == 0xFFFFFFFFu) ? (int8_t)-1 : (int8_t)(v >> 24);
-                    const int L = lensL[r];
+                    const int L = lensC[r];
                     const EndGeom g = end_geom(L, S);
                     int last_abs = -0x7FFFFFFF;
                     if (v != 0xFFFFFFFFu) {
@@ -1368,7 +1296,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                         dbg_bdist[(size_t)r0 * H * maxB + (size_t)item * maxB + i] =
                             (br[i] == 0xFFFFFFFFu) ? (int8_t)-1 : (int8_t)(br[i] >> 24);
                 if (best == 255) continue;
-                int L = lensL[r];
+                int L = lensC[r];
                 EndGeom g = end_geom(L, S);
                 int ntied = 0, first = -1, tail = -0x7FFFFFFF;
                 for (int i = 0; i < nb; i++) {
@@ -1395,11 +1323,19 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             q0 = q1;
         }
 
-        // ---- phase 4: scorer, one lane per read (reads spread over the 4 waves)
-        {
-            int r = tid;   // reads packed into the lowest waves: the other waves just wait at the barrier
+        }   // have
+        // the encode target buffers: namask is OR-ed into, the next tile's orientation votes are counted up
+        for (int i = tid; i < R * 2 * (MW + 1); i += NT) namask[i] = 0;
+        for (int i = tid; i < 2 * R; i += NT) ocnt[(par ^ 1) * 2 * R + i] = 0;
+        __syncthreads();
+        const uint32_t nxt = (uint32_t)aggr[9];
+
+        // ---- phase 4 || phase 1: the scorer of this tile (lowest wave(s), one lane per read) runs beside the
+        // load + encode of the next tile (all other waves; every wave while the pipeline fills)
+        if (have && wave < SW) {
+            int r = tid;
             if (r < nr) {
-                int L = lensL[r];
+                int L = lensC[r];
                 bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
 #if !(defined(SMX_EXP) && (SMX_EXP == 3 || SMX_EXP == 4))
                 atomicAdd(&aggr[0], 1);
@@ -1415,7 +1351,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     ReadCtx c;
                     c.P = P; c.LP = LP; c.hits = hits + r * H; c.tiem = tiem + r * H * MBW; c.MBW = MBW; c.L = L; c.S = S;
                     c.g = end_geom(L, S);
-                    int f = ocnt[2 * r], rv = ocnt[2 * r + 1];
+                    int f = ocntC[2 * r], rv = ocntC[2 * r + 1];
                     int ori = 3;
                     if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
                     Emitter E;
@@ -1453,21 +1389,95 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     }
                 }
             }
+        } else if (nxt < n_tiles) {
+            // ---- phase 1 (of the NEXT tile): windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
+            const int wid = have ? tid - 64 * SW : tid, nw = have ? NT - 64 * SW : NT;
+            const uint32_t r0n = nxt * R;
+            const int nrn = (int)((n_reads - r0n) < (uint32_t)R ? (n_reads - r0n) : (uint32_t)R);
+            int *lensN = lensL + (par ^ 1) * R;
+            if (wid < nrn) lensN[wid] = lens[r0n + wid];
+            // one 16-byte chunk: generic per-byte encode (short reads, search_len not a multiple of 16)
+            auto encode_bytes = [&](int r, int L, int cpos, const uint4 &v) {
+                int Sp = L < S ? L : S;
+                unsigned w[4] = {v.x, v.y, v.z, v.w};
+                unsigned char *rowA = codes + (r * 2 + 0) * CS, *rowB = codes + (r * 2 + 1) * CS;
+                for (int b = 0; b < 16; b++) {
+                    int pos = cpos + b;
+                    unsigned ch = (w[b >> 2] >> ((b & 3) * 8)) & 0xFF;
+                    if (pos < S) {            // head byte i -> A[Sp-1-i] = code(complement)
+                        if (pos < Sp) {
+                            unsigned cd = lut[256 + ch];
+                            int j = Sp - 1 - pos;
+                            rowA[j] = (unsigned char)cd;
+                            if (cd > 3) atomicOr(&namask[(r * 2 + 0) * (MW + 1) + (j >> 5)], 1u << (j & 31));
+                        }
+                    } else if (pos < 2 * S) { // tail byte j -> B[j]
+                        int j = pos - S;
+                        if (j < Sp) {
+                            unsigned cd = lut[ch];
+                            rowB[j] = (unsigned char)cd;
+                            if (cd > 3) atomicOr(&namask[(r * 2 + 1) * (MW + 1) + (j >> 5)], 1u << (j & 31));
+                        }
+                    }
+                }
+            };
+            if ((S & 15) == 0) {
+                // fast path: chunks never straddle the head/tail boundary; items are ordered [all head chunks]
+                // [all tail chunks] so that a wave is (almost always) uniform in role.  Full windows (len >= S):
+                // four LUT lookups -> one packed dword store; the head is written reversed (reverse complement).
+                const int hc = S >> 4, nhead = nrn * hc, S4 = S >> 2;
+                for (int ci = wid; ci < 2 * nhead; ci += nw) {
+                    const bool tail = ci >= nhead;
+                    const int k = tail ? ci - nhead : ci;
+                    const int r = k / hc, c = k - r * hc;
+                    const uint4 v = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (tail ? S : 0) + 16 * c);
+                    const int L = lens[r0n + r];
+                    if (L >= S) {
+                        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                        const unsigned char *lt = lut + (tail ? 0 : 256);
+                        unsigned *dst = (unsigned *)(codes + (r * 2 + (tail ? 1 : 0)) * CS);
+                        unsigned any = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            unsigned c0 = lt[w[q] & 0xFF], c1 = lt[(w[q] >> 8) & 0xFF], c2 = lt[(w[q] >> 16) & 0xFF], c3 = lt[w[q] >> 24];
+                            unsigned packed = tail ? (c0 | (c1 << 8) | (c2 << 16) | (c3 << 24))
+                                                   : (c3 | (c2 << 8) | (c1 << 16) | (c0 << 24));
+                            dst[tail ? 4 * c + q : S4 - 1 - (4 * c + q)] = packed;
+                            any |= packed;
+                        }
+                        if (any & 0x0C0C0C0Cu) {   // rare: a non-ACGT base in this chunk -> flag it for the prefilter rule
+                            const unsigned char *row = (const unsigned char *)dst;
+                            const int j0 = tail ? 16 * c : S - 16 * c - 16;
+                            for (int j = j0; j < j0 + 16; j++)
+                                if (row[j] > 3) atomicOr(&namask[(r * 2 + (tail ? 1 : 0)) * (MW + 1) + (j >> 5)], 1u << (j & 31));
+                        }
+                    } else {
+                        encode_bytes(r, L, (tail ? S : 0) + 16 * c, v);
+                    }
+                }
+            } else {
+                const int chunks = stride / 16;
+                const uint4 *src = (const uint4 *)(windows + (size_t)r0n * stride);
+                for (int ci = wid; ci < nrn * chunks; ci += nw) {
+                    int r = ci / chunks;
+                    encode_bytes(r, lens[r0n + r], (ci - r * chunks) * 16, src[ci]);
+                }
+            }
         }
         __syncthreads();
         STAMP(6);
         // result records: LDS -> HBM, 16 bytes per lane, fully coalesced
-        {
+        if (have) {
             const uint4 *srcv = (const uint4 *)opsL;
             uint4 *dstv = (uint4 *)(ops + r0);
             for (int i = tid; i < nr * 2; i += NT) dstv[i] = srcv[i];
         }
         // ---- optional parity dump
-        if (dbg_hits) {
+        if (have && dbg_hits) {
             for (int item = tid; item < nh; item += NT) {
                 int r = item / H;
                 const HitL &hl = hits[item];
-                EndGeom g = end_geom(lensL[r], S);
+                EndGeom g = end_geom(lensC[r], S);
                 smx_hit o;
                 o.pdist = hl.pdist; o.nloc = hl.nloc;
                 o.first_start = hl.pdist >= 0 ? (int)hl.fs_j - g.j_lo + g.shift : -1;
@@ -1479,8 +1489,12 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 dbg_hits[(size_t)(r0 + r) * H + (item - r * H)] = o;
             }
         }
-        __syncthreads();
+        if (dbg_hits) __syncthreads();   // the dump reads hits[]; the next tile's primer scan rewrites them
         STAMP(7);
+        if (nxt >= n_tiles) break;   // nothing was encoded: the queue is drained
+        cur = nxt;
+        par ^= 1;
+        // (no barrier needed here: the next writers of hits / masks / opsL come after the barriers of phase 2)
     }
     if (timing)
         for (int i = 0; i < 10; i++) P->dbg_phase[(size_t)blockIdx.x * 16 + i] += tacc[i];

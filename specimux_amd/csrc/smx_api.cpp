@@ -235,10 +235,10 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
         for (int p = 0; p < NP; p++)
             for (int li = pbc_off[p]; li < pbc_off[p + 1]; li++) {
                 int gb = pbc[li], bi = li - pbc_off[p];
-                for (int row = 0; row < bm[gb]; row++)
+                for (int row = 0; row < 16; row++)   // rows past the barcode are wildcards (bitsliced_shw_pad)
                     for (int c = 0; c < 16; c++)
-                        if ((bpeq[gb * 16 + c] >> row) & 1u)
-                            bsre[(((size_t)p * 16 + row) * 16 + c) * MBWh + (bi >> 5)] |= 1u << (bi & 31);
+                        if (row >= bm[gb] || ((bpeq[gb * 16 + c] >> row) & 1u))
+                            bsre[((((size_t)p * MBWh + (bi >> 5)) * 16 + row) * 16 + c)] |= 1u << (bi & 31);   // [primer][word][row][code]
             }
     h.bs_ok = bs_ok ? 1 : 0;
     if (const char *e = getenv("SMX_TEST_CAPS")) sscanf(e, "%d,%d", &h.cap_hits, &h.cap_ents);
@@ -290,14 +290,13 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     size_t budget = 40 * 1024;   // 4 workgroups per CU (VGPR-limited to 4 waves/SIMD anyway)
     if (const char *e = getenv("SMX_LDS_BUDGET")) budget = (size_t)atol(e);
     int rmax = 64;
-    if (const char *e = getenv("SMX_TILE_R")) rmax = std::max(1, std::min(128, atoi(e)));
+    if (const char *e = getenv("SMX_TILE_R")) rmax = std::max(1, std::min(64, atoi(e)));
     const int npmeta = 5 * NP + 1 + h.n_pbc + NB + 3 * NPAIR;
     for (int slots = 0; slots < 2; slots++)
         for (int R = rmax; R >= 1; R >>= 1) {
             size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, slots,
                                               h.bs_ok);
-            // 128-read tiles run on 512-thread workgroups: two of those per CU
-            if (need <= (R > 64 ? 2 * budget : budget) || R == 1) {
+            if (need <= budget || R == 1) {
                 if (slots) { P->R_slots = R; P->lds_slots = need; } else { P->R = R; P->lds = need; }
                 break;
             }

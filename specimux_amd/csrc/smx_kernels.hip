@@ -173,8 +173,8 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.ppeq = o;  o += t.NPs * 16 * (int)sizeof(PW);
     t.prpeq = o; o += (need_starts ? t.NPs * 16 * (int)sizeof(PW) : 0);
     t.bpeq = o;  o += (bs && !slots) ? 0 : t.NBs * 16 * 4;
-    t.BSP = (16 * 16 + 4) * t.MBW;              // words per primer in the bit-sliced table (+4: bank skew)
-    t.bsre = o;  o += (bs && !slots) ? NP * t.BSP * 4 : 0;
+    t.BSP = 16 * 16 + 4;                        // words per (primer, 32-barcode word) block of the bit-sliced table (+4: bank skew)
+    t.bsre = o;  o += (bs && !slots) ? NP * t.MBW * t.BSP * 4 : 0;
     t.lut = o;   o += 512;
     t.pmeta = o; o += npmeta * 4;
     o = (o + 15) & ~15;
@@ -253,7 +253,7 @@ __device__ __forceinline__ int nth_location(const unsigned *mrow, int MW, int js
 // while the band's bottom edge is still descending (c + k <= m - 1) the bottom cell has no left neighbour and
 // B_c = B_(c-1) + (1 - Z); once it sits on the last row, B_c = B_(c-1) + (Ph - Mh) as in the full DP.  B_0 = k.
 template <int KL>   // KL = number of distance levels kept (k + 1 <= KL): 4 or 8
-__device__ __forceinline__ void bitsliced_shw(const unsigned *re, int MBW, const unsigned char *cw, int ncol, int m,
+__device__ __forceinline__ void bitsliced_shw(const unsigned *re, const unsigned char *cw, int ncol, int m,
                                               int kidx, unsigned (&seen)[KL]) {
     unsigned Pv[16], Mv[16];
 #pragma unroll
@@ -263,10 +263,11 @@ __device__ __forceinline__ void bitsliced_shw(const unsigned *re, int MBW, const
              s4 = (b0 & 16) ? ~0u : 0u;
 #pragma unroll
     for (int d = 0; d < KL; d++) seen[d] = 0u;
-    const int ncols = m + kidx, rs = 16 * MBW;
+    const int ncols = m + kidx;
+    constexpr int rs = 16;   // table block layout [row][code]
     for (int c = 0; c < ncols; c++) {
         const unsigned code = c < ncol ? (unsigned)cw[c] : 15u;   // past the window: code 15 matches nothing
-        const unsigned *rc = re + code * MBW;
+        const unsigned *rc = re + code;
         const int rlo = c - kidx, rhi = (c + kidx < m - 1) ? c + kidx : m - 1;   // in-band rows of this column
         const unsigned rows = (rhi >= 0 ? (2u << rhi) - 1u : 0u) & (rlo > 0 ? ~0u << rlo : ~0u);   // one scalar test per row
         unsigned Ph = ~0u, Mh = 0u, Zb = 0u;
@@ -311,74 +312,81 @@ __device__ __forceinline__ void bitsliced_shw(const unsigned *re, int MBW, const
     }
 }
 
-// Same banded DP with a fixed band half-width KB >= k and the 2*KB+1 live rows kept in a circular register
-// window (row r lives in slot r mod WIN).  The column loop is unrolled by WIN so every slot index is static:
-// 14 state registers for KB = 3 instead of 32.  A wider band than k is still exact (it contains the k band).
-template <int KB>
-__device__ __forceinline__ void bitsliced_shw_win(const unsigned *re, int MBW, const unsigned char *cw, int ncol, int m,
+// Banded DP with a fixed band half-width KB >= k (a wider band than k is still exact: it contains the k band); the
+// 2*KB+1 live rows are kept in a circular register window (row r lives in slot r mod WIN, all slot indices static).
+// Every barcode is PADDED to M rows by wildcard rows (Eq = all ones for every text code, also
+// past the end of the window): the loop bounds no longer depend on the barcode length, so the whole scan unrolls into
+// straight-line code -- static row tests, LDS reads at immediate offsets issued ahead of their use, no scalar branches.
+// Exactness: a path that reaches (m, j) continues for free along its diagonal to (M, j + M - m), and every other way
+// into row M costs at least as much, so min over the live columns of row M equals min over the live columns of row m;
+// the lean summary only ever uses that minimum (the lowest non-empty distance level and its bits).  Column c' of row M
+// is live iff c' - (M - m) lies inside the window.  M + KB columns instead of m + k: 19 vs 16 for 13-nt barcodes, at
+// less than half the instructions per column.
+template <int KB, int M>
+__device__ __forceinline__ void bitsliced_shw_pad(const unsigned *re, const unsigned char *cw, int ncol, int m,
                                                   int kidx, unsigned (&seen)[KB + 1]) {
-    constexpr int WIN = 2 * KB + 1;
+    constexpr int WIN = 2 * KB + 1, NC = M + KB;
+    static_assert(KB < M && M <= 16, "band / padding out of range");
     unsigned Pw[WIN], Mw[WIN];
 #pragma unroll
     for (int i = 0; i < WIN; i++) { Pw[i] = ~0u; Mw[i] = 0u; }
-    const int b0 = KB < m ? KB : m;   // D(bottom in-band row of column 0)
+    constexpr int b0 = KB;   // D(bottom in-band row of column 0)
     unsigned s0 = (b0 & 1) ? ~0u : 0u, s1 = (b0 & 2) ? ~0u : 0u, s2 = (b0 & 4) ? ~0u : 0u, s3 = (b0 & 8) ? ~0u : 0u,
-             s4 = (b0 & 16) ? ~0u : 0u;
+             s4 = 0u;
 #pragma unroll
     for (int d = 0; d <= KB; d++) seen[d] = 0u;
-    const int ncols = m + kidx, rs = 16 * MBW;
-    for (int c0 = 0; c0 < ncols; c0 += WIN) {
+    constexpr int rs = 16;   // table block layout [row][code]: every Eq read is base + code at an immediate offset
+    const int nlive = ncol + (M - m);
 #pragma unroll
-        for (int u = 0; u < WIN; u++) {
-            const int c = c0 + u;
-            if (c < ncols) {
-                const unsigned code = c < ncol ? (unsigned)cw[c] : 15u;
-                const unsigned *rc = re + code * MBW;
-                // the row entering the band (c + KB) takes the slot of the row that left it: back to the initial delta
-                Pw[(u + KB) % WIN] = ~0u; Mw[(u + KB) % WIN] = 0u;
-                unsigned Ph = ~0u, Mh = 0u, Zb = 0u;
+    for (int c = 0; c < NC; c++) {
+        // unconditional read (past the window it hits other LDS bytes, never out of the allocation's reach: rows are
+        // followed by >= 32 bytes of other regions) + select: no branch, so the column stays one basic block
+        const unsigned raw = (unsigned)cw[c];
+        const unsigned code = c < ncol ? raw : 15u;
+        const unsigned *rc = re + code;
+        Pw[(c + KB) % WIN] = ~0u; Mw[(c + KB) % WIN] = 0u;   // the row entering the band: initial vertical delta
+        unsigned Ph = ~0u, Mh = 0u, Zb = 0u;
 #pragma unroll
-                for (int w = 0; w < WIN; w++) {
-                    const int row = c - KB + w;                // slot = row mod WIN = (u - KB + w) mod WIN, static
-                    const int sl = ((u - KB + w) % WIN + WIN) % WIN;
-                    if (row >= 0 && row < m) {
-                        const unsigned Eq = rc[row * rs];
-                        const unsigned Z = Eq | Mh | Mw[sl];
-                        const unsigned nPh = Mw[sl] | ~(Z | Pw[sl]);
-                        const unsigned nMh = Pw[sl] & Z;
-                        const unsigned nPv = Mh | ~(Z | Ph);
-                        const unsigned nMv = Ph & Z;
-                        Pw[sl] = nPv; Mw[sl] = nMv; Ph = nPh; Mh = nMh;
-                        Zb = Z;
-                    }
-                }
-                const bool descending = c + KB <= m - 1;   // uniform: the bottom edge has not reached the last row yet
-                {
-                    unsigned cy = descending ? ~Zb : Ph, t;
-                    t = s0 & cy; s0 ^= cy; cy = t;
-                    t = s1 & cy; s1 ^= cy; cy = t;
-                    t = s2 & cy; s2 ^= cy; cy = t;
-                    t = s3 & cy; s3 ^= cy; cy = t;
-                    s4 ^= cy;
-                }
-                if (!descending) {   // only the last row can lose a unit
-                    unsigned bw = Mh, t;
-                    t = ~s0 & bw; s0 ^= bw; bw = t;
-                    t = ~s1 & bw; s1 ^= bw; bw = t;
-                    t = ~s2 & bw; s2 ^= bw; bw = t;
-                    t = ~s3 & bw; s3 ^= bw; bw = t;
-                    s4 ^= bw;
-                }
-                if (c >= m - KB - 1) {   // the tracked cell sits on the last row from here on
-                    const unsigned live = c < ncol ? ~0u : 0u;
-                    const unsigned hi = ~(s4 | s3) & live;
-#pragma unroll
-                    for (int d = 0; d <= KB; d++)
-                        if (d <= kidx)
-                            seen[d] |= hi & ((d & 1) ? s0 : ~s0) & ((d & 2) ? s1 : ~s1) & ((d & 4) ? s2 : ~s2);
-                }
+        for (int w = 0; w < WIN; w++) {
+            const int row = c - KB + w;
+            const int sl = ((row % WIN) + WIN) % WIN;
+            if (row >= 0 && row < M) {
+                const unsigned Eq = rc[row * rs];
+                const unsigned Z = Eq | Mh | Mw[sl];
+                const unsigned nPh = Mw[sl] | ~(Z | Pw[sl]);
+                const unsigned nMh = Pw[sl] & Z;
+                const unsigned nPv = Mh | ~(Z | Ph);
+                const unsigned nMv = Ph & Z;
+                Pw[sl] = nPv; Mw[sl] = nMv; Ph = nPh; Mh = nMh;
+                Zb = Z;
             }
         }
+        const bool descending = c + KB <= M - 1;
+        {
+            unsigned cy = descending ? ~Zb : Ph, t;
+            t = s0 & cy; s0 ^= cy; cy = t;
+            t = s1 & cy; s1 ^= cy; cy = t;
+            t = s2 & cy; s2 ^= cy; cy = t;
+            t = s3 & cy; s3 ^= cy; cy = t;
+            s4 ^= cy;
+        }
+        if (!descending) {
+            unsigned bw = Mh, t;
+            t = ~s0 & bw; s0 ^= bw; bw = t;
+            t = ~s1 & bw; s1 ^= bw; bw = t;
+            t = ~s2 & bw; s2 ^= bw; bw = t;
+            t = ~s3 & bw; s3 ^= bw; bw = t;
+            s4 ^= bw;
+        }
+        if (c >= M - KB - 1) {   // the tracked cell sits on the last row from here on
+            const unsigned live = c < nlive ? ~0u : 0u;
+            const unsigned hi = ~(s4 | s3) & live;
+#pragma unroll
+            for (int d = 0; d <= KB; d++)
+                if (d <= kidx)
+                    seen[d] |= hi & ((d & 1) ? s0 : ~s0) & ((d & 2) ? s1 : ~s1) & ((d & 4) ? s2 : ~s2);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the live ranges column-sized (otherwise ~130 LDS reads get hoisted and spill)
     }
 }
 
@@ -814,7 +822,9 @@ __device__ inline void score_general(Emitter &E, int ori) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename PW, int NT>   // NT threads per workgroup: 256 (tiles up to 64 reads) or 512 (128 reads)
+// BSV selects the barcode scan compiled into the kernel (one variant per kernel keeps their register allocations
+// apart): 0 = per-barcode bit-vector scan only, 1 = bit-sliced, k <= 3 (padded 7-row window), 2 = bit-sliced, k 4..7.
+template <typename PW, int NT, int BSV>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
 __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
@@ -827,7 +837,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
     const int n_pbc = P->n_pbc, NPAIR = P->NPAIR;
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
-    const int use_bs = (P->bs_ok && !use_slots) ? 1 : 0;
+    const int use_bs = (BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0;
     const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta, P->kidx, use_slots, P->bs_ok,
                                          P->cap_hits, P->cap_ents);
     PW *ppeq = (PW *)(lds + T.ppeq);        // [code][primer], stride NPs
@@ -865,9 +875,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     if (!use_bs)
         for (int i = tid; i < NB * 16; i += NT) bpeq[(i & 15) * NBs + (i >> 4)] = P->bpeq[i];
     if (use_bs)
-        for (int i = tid; i < NP * 16 * 16 * T.MBW; i += NT) {
-            int p = i / (256 * T.MBW);
-            bsre[p * T.BSP + (i - p * 256 * T.MBW)] = P->bs_re[i];
+        for (int i = tid; i < NP * T.MBW * 256; i += NT) {
+            int blk = i >> 8;   // (primer, word) block: [row][code], the row stride is a compile-time 16 words
+            bsre[blk * T.BSP + (i & 255)] = P->bs_re[i];
         }
     for (int i = tid; i < 512; i += NT) lut[i] = P->lut[i];
     int *pmeta = (int *)(lds + T.pmeta);
@@ -899,7 +909,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     unsigned long long *tacc = (unsigned long long *)(lds + T.tacc);   // [0..9] sums, [10] previous stamp
     const bool timing = P->dbg_phase != nullptr && tid == 0;
     if (timing) for (int i = 0; i < 11; i++) tacc[i] = 0;
-#define STAMP(i) do { if (timing) { unsigned long long _t = clock64(); tacc[i] += _t - tacc[10]; tacc[10] = _t; } } while (0)
+// STAMP marks a phase boundary: optional timing, and tid is laundered so that per-thread values are recomputed by
+// the phase that needs them instead of being computed early and carried (spilled) across the register-hungry scans
+#define STAMP(i) do { asm volatile("" : "+v"(tid)); if (timing) { unsigned long long _t = clock64(); tacc[i] += _t - tacc[10]; tacc[10] = _t; } } while (0)
     // dynamic tile queue: workgroups pull tiles from a global counter (zeroed on the stream before the
     // launch), so the tail is one tile long whatever the residency turns out to be
     // Software pipeline over tiles: while the lowest wave(s) run the scorer of tile t (one lane per read), the other
@@ -930,6 +942,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             PW Pvv = ~(PW)0, Mv = 0;
             int score = m, best = m + 1, jstar = 0, cnt = 0;
             unsigned *mrow = masks + (size_t)item * MW;
+#if defined(SMX_EXP) && SMX_EXP == 7
+            g.Sp = 0; g.j_lo = 1;   // timing experiment: no primer columns
+#endif
             if (sizeof(PW) == 4 && g.j_lo == 0 && (g.Sp & 3) == 0 && g.Sp > 0) {
                 // common case, 32-bit patterns: four columns per group, the next group's Eq words are fetched
                 // before the current group is computed (the compiler otherwise waits on every LDS read), and the
@@ -1085,7 +1100,11 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         __syncthreads();
         for (int item = tid; item < nh; item += NT)
             if (offsB[item + 1] != offsB[item]) queue[offsB[item]] = (unsigned short)item;
+#if defined(SMX_EXP) && SMX_EXP == 6
+        const int nq = 0;
+#else
         const int nq = offsB[nh];
+#endif
         __syncthreads();
         STAMP(2);
 
@@ -1157,8 +1176,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             __syncthreads();
             STAMP(3);
 
-            // 3b (lean, uniform barcode length): bit-sliced scan, one lane per (entry, 32-barcode word)
-            if (use_bs) {
+            // 3b (lean, uniform barcode length): bit-sliced scan, one lane per (entry, 32-barcode word).  Two separate
+            // loops (k is uniform for the launch) so that the register allocation of one variant never meets the other's.
+            if (BSV != 0 && use_bs) {
                 const int bsm = P->bs_m;
                 for (int item = tid; item < nE * MBW; item += NT) {
                     const int ei = item / MBW, w = item - ei * MBW;
@@ -1167,15 +1187,15 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     const int hh = en.hit, h = hh % H, p = h >> 1, X = h & 1, r = hh / H;
                     const unsigned char *cwt = codes + (r * 2 + X) * CS + en.tj0;
                     unsigned *dm = dmask + ((en.slot >> logG) * (kidx + 1)) * MBW + w;
-                    if (kidx < 4) {
+                    if constexpr (BSV == 1) {
                         unsigned seen[4];
-                        bitsliced_shw_win<3>(bsre + p * T.BSP + w, MBW, cwt, en.ncol, bsm, kidx, seen);
+                        bitsliced_shw_pad<3, 16>(bsre + (p * MBW + w) * T.BSP, cwt, en.ncol, bsm, kidx, seen);
 #pragma unroll
                         for (int d = 0; d < 4; d++)
                             if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
-                    } else {
+                    } else if constexpr (BSV == 2) {
                         unsigned seen[8];
-                        bitsliced_shw<8>(bsre + p * T.BSP + w, MBW, cwt, en.ncol, bsm, kidx, seen);
+                        bitsliced_shw<8>(bsre + (p * MBW + w) * T.BSP, cwt, en.ncol, bsm, kidx, seen);
 #pragma unroll
                         for (int d = 0; d < 8; d++)
                             if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
@@ -1334,7 +1354,13 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         // load + encode of the next tile (all other waves; every wave while the pipeline fills)
         if (have && wave < SW) {
             int r = tid;
+#if defined(SMX_EXP) && SMX_EXP == 5
+            if (r < nr) { smx_op op; op.sample = -1; op.trim_start = 0; op.trim_end = lensC[r]; op.pool = -1; op.p1 = op.p2 = -1; op.barcode = -1;
+                op.dist[0] = op.dist[1] = op.dist[2] = op.dist[3] = -1; op.rtype = SMX_R_UNKNOWN; op.flags = 0; op.n_ops = 1; op.read = r0 + r; opsL[r] = op; }
+            if (false) {
+#else
             if (r < nr) {
+#endif
                 int L = lensC[r];
                 bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
 #if !(defined(SMX_EXP) && (SMX_EXP == 3 || SMX_EXP == 4))
@@ -1588,13 +1614,15 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
     // d_tile_counter[0] = tile queue head, [1] = number of deferred reads
     hipError_t me = hipMemsetAsync(d_tile_counter, 0, 2 * sizeof(unsigned), s);
     if (me != hipSuccess) return (int)me;
-    // tiles of up to 64 reads run on 256-thread workgroups, tiles of 128 reads on 512-thread workgroups
-#define SMX_LAUNCH(PWT, NTV)                                                                                          \
-    hipLaunchKernelGGL((smx::demux_kernel<PWT, NTV>), dim3(grid), dim3(NTV), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
+    // one instantiation per (primer word width, barcode scan variant); slots mode never uses the bit-sliced scan
+    const int bsv = (use_slots || !P->bs_ok) ? 0 : (P->kidx < 4 ? 1 : 2);
+#define SMX_LAUNCH(PWT, BSVV)                                                                                         \
+    hipLaunchKernelGGL((smx::demux_kernel<PWT, 256, BSVV>), dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
                        d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits, d_bdist,        \
                        d_tile_counter, use_slots, d_defer, d_tile_counter + 1)
-    if (R > 64) { if (use64) SMX_LAUNCH(unsigned long long, 512); else SMX_LAUNCH(unsigned, 512); }
-    else { if (use64) SMX_LAUNCH(unsigned long long, 256); else SMX_LAUNCH(unsigned, 256); }
+    if (R > 64) return (int)hipErrorInvalidValue;
+    if (use64) { if (bsv == 0) SMX_LAUNCH(unsigned long long, 0); else if (bsv == 1) SMX_LAUNCH(unsigned long long, 1); else SMX_LAUNCH(unsigned long long, 2); }
+    else { if (bsv == 0) SMX_LAUNCH(unsigned, 0); else if (bsv == 1) SMX_LAUNCH(unsigned, 1); else SMX_LAUNCH(unsigned, 2); }
 #undef SMX_LAUNCH
     me = hipGetLastError();
     if (me != hipSuccess) return (int)me;
@@ -1613,8 +1641,10 @@ extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, i
 
 extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
     hipError_t e = hipSuccess;
-    const void *fns[2] = {use64 ? (const void *)smx::demux_kernel<unsigned long long, 256> : (const void *)smx::demux_kernel<unsigned, 256>,
-                          use64 ? (const void *)smx::demux_kernel<unsigned long long, 512> : (const void *)smx::demux_kernel<unsigned, 512>};
+    const void *fns[3] = {
+        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 0> : (const void *)smx::demux_kernel<unsigned, 256, 0>,
+        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 1> : (const void *)smx::demux_kernel<unsigned, 256, 1>,
+        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 2> : (const void *)smx::demux_kernel<unsigned, 256, 2>};
     for (const void *f : fns) {
         hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (r != hipSuccess) e = r;
@@ -1627,8 +1657,8 @@ extern "C" size_t smx_deferred_rec_bytes(int NP, int maxB) {   // 0: the build k
 }
 
 extern "C" int smx_query_occupancy(int use64, size_t lds_bytes, int *blocks_per_cu) {
-    hipError_t e = use64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, smx::demux_kernel<unsigned long long, 256>, 256, lds_bytes)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, smx::demux_kernel<unsigned, 256>, 256, lds_bytes);
+    hipError_t e = use64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, smx::demux_kernel<unsigned long long, 256, 1>, 256, lds_bytes)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, smx::demux_kernel<unsigned, 256, 1>, 256, lds_bytes);
     return (int)e;
 }
 

@@ -655,6 +655,7 @@ __device__ inline bool score_fast(Emitter &E, int ori) {
     bool has_v = true;
     int pair = only_pair, o = only_o, sample = -1, rtype = SMX_R_UNKNOWN, barcode = -1, pool = -2;   // pool -2: the pair's
     unsigned xflags = 0;
+    int more1 = -1, more2 = -1, more3 = -1;   // further specimens of a tied full match
     if (best == 0) {   // no candidate at all (demultiplex.py:202-210)
         has_v = false; pair = 0; o = 0; pool = -1;
     } else if (best <= 2 && nbest > 1) {
@@ -678,21 +679,46 @@ __device__ inline bool score_fast(Emitter &E, int ori) {
         const bool t1 = !v.b1 || a.ntied == 1, t2 = !v.b2 || b.ntied == 1;
         if (best <= 2) {
             // dereplicate_unknown_matches / resolve_specimen: UNKNOWN either way
-        } else if (!(t1 && t2)) {
-            return false;
         } else if (best <= 4) {   // one (direction, barcode) group: resolve_specimen (demultiplex.py:576-589)
+            if (!(t1 && t2)) return false;
             if (v.b1 && !v.b2) { rtype = SMX_R_PARTIAL_FWD; barcode = global_bc(c, v.h1, a.first_tied); }
             else if (v.b2 && !v.b1) { rtype = SMX_R_PARTIAL_REV; barcode = global_bc(c, v.h2, b.first_tied); }
         } else {
             if (P->derep != SMX_DEREP_BEST) return false;
-            int spec = specimen_exact(P, global_bc(c, v.h1, a.first_tied), global_bc(c, v.h2, b.first_tied), v.f, v.r);
-            if (spec >= 0) { sample = spec; rtype = SMX_R_DEREP_FULL; pool = P->spec_pool[spec]; }
-            else xflags = SMX_OPF_NO_SPECIMEN;
+            if (t1 && t2) {
+                int spec = specimen_exact(P, global_bc(c, v.h1, a.first_tied), global_bc(c, v.h2, b.first_tied), v.f, v.r);
+                if (spec >= 0) { sample = spec; rtype = SMX_R_DEREP_FULL; pool = P->spec_pool[spec]; }
+                else xflags = SMX_OPF_NO_SPECIMEN;
+            } else {
+                // one candidate, tied barcodes (by far the most frequent reason to leave the single-record path):
+                // dereplicate_matches (demultiplex.py:262-393) with one member per group = one DEREP_FULL record per
+                // distinct specimen among the tied (b1, b2) combinations, in first-appearance order
+                int s0 = -1, s1 = -1, s2 = -1, s3 = -1, ns = 0;
+                for (int i = next_tied(c, v.h1, 0); i >= 0; i = next_tied(c, v.h1, i + 1))
+                    for (int j = next_tied(c, v.h2, 0); j >= 0; j = next_tied(c, v.h2, j + 1)) {
+                        int sp = specimen_exact(P, global_bc(c, v.h1, i), global_bc(c, v.h2, j), v.f, v.r);
+                        if (sp < 0 || sp == s0 || sp == s1 || sp == s2 || sp == s3) continue;
+                        if (ns == 4) return false;   // more groups than this path keeps: the general scorer takes over
+                        if (ns == 0) s0 = sp; else if (ns == 1) s1 = sp; else if (ns == 2) s2 = sp; else s3 = sp;
+                        ns++;
+                    }
+                if (ns == 0) xflags = SMX_OPF_NO_SPECIMEN;
+                else {
+                    sample = s0; rtype = SMX_R_DEREP_FULL; pool = P->spec_pool[s0];
+                    more1 = s1; more2 = s2; more3 = s3;
+                }
+            }
         }
     }
     if (pool == -2) pool = c.LP.pair_pool[pair];
     const CandView v = cand_view(c, pair, o);
     emit_op(E, has_v ? &v : nullptr, pair * 2 + o, sample, rtype, pool, barcode, xflags);
+    if (more1 >= 0) {   // rare
+        for (int e = 0; e < 3; e++) {
+            int sp = e == 0 ? more1 : (e == 1 ? more2 : more3);
+            if (sp >= 0) emit_op(E, &v, pair * 2 + o, sp, SMX_R_DEREP_FULL, P->spec_pool[sp], -1, 0);
+        }
+    }
     return true;
 }
 
@@ -1418,6 +1444,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         } else if (nxt < n_tiles) {
             // ---- phase 1 (of the NEXT tile): windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
             const int wid = have ? tid - 64 * SW : tid, nw = have ? NT - 64 * SW : NT;
+            const bool timing_enc = P->dbg_phase != nullptr && tid == 64 * SW;   // diagnostic: this wave's own encode time
+            unsigned long long t_enc0 = 0;
+            if (timing_enc) t_enc0 = clock64();
             const uint32_t r0n = nxt * R;
             const int nrn = (int)((n_reads - r0n) < (uint32_t)R ? (n_reads - r0n) : (uint32_t)R);
             int *lensN = lensL + (par ^ 1) * R;
@@ -1489,6 +1518,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     encode_bytes(r, lens[r0n + r], (ci - r * chunks) * 16, src[ci]);
                 }
             }
+            if (timing_enc) tacc[8] += clock64() - t_enc0;
         }
         __syncthreads();
         STAMP(6);

@@ -315,13 +315,12 @@ void smx_panel_destroy(smx_panel *P) {
             unsigned long long sum[10] = {0}, tot = 0;
             for (int b = 0; b < P->phase_grid; b++)
                 for (int i = 0; i < 10; i++) { sum[i] += h[(size_t)b * 16 + i]; tot += h[(size_t)b * 16 + i]; }
-            const char *names[8] = {"load+encode", "primer_scan", "orient+scan", "entries", "barcode_scan", "summary",
+            const char *names[8] = {"zero+barrier", "primer_scan", "orient+scan", "entries", "barcode_scan", "summary",
                                     "scorer||encode", "store"};
             fprintf(stderr, "[smx phase timing] R=%d lds=%zu blocks/CU=%d:", P->R, P->lds, P->blocks_per_cu);
-            tot -= sum[8] + sum[9];   // [8] = the first encode wave's own encode time (inside the scorer||encode region), [9] = experiment probe
+            tot -= sum[8] + sum[9];   // [8] = the first encode wave's own encode time (inside the scorer||encode region), [9] = the scorer wave's own time
             for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.1f%%", names[i], tot ? 100.0 * sum[i] / tot : 0.0);
-            fprintf(stderr, " (encode wave alone=%.1f%%, probe=%.1f%% raw=%llu = %llu %llu %llu %llu)", tot ? 100.0 * sum[8] / tot : 0.0, tot ? 100.0 * sum[9] / tot : 0.0, sum[9],
-                    sum[9] & 0xFFFF, (sum[9] >> 16) & 0xFFFF, (sum[9] >> 32) & 0xFFFF, sum[9] >> 48);
+            fprintf(stderr, " (inside the region: scorer wave %.1f%%, first encode wave %.1f%%)", tot ? 100.0 * sum[9] / tot : 0.0, tot ? 100.0 * sum[8] / tot : 0.0);
             fprintf(stderr, "\n");
             if (getenv("SMX_DEBUG")) {   // where did wave w of each workgroup land?  hist[w][simd]
                 int hist[4][4] = {{0}};

@@ -1375,10 +1375,13 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         for (int i = tid; i < 2 * R; i += NT) ocnt[(par ^ 1) * 2 * R + i] = 0;
         __syncthreads();
         const uint32_t nxt = (uint32_t)aggr[9];
+        STAMP(0);
 
         // ---- phase 4 || phase 1: the scorer of this tile (lowest wave(s), one lane per read) runs beside the
         // load + encode of the next tile (all other waves; every wave while the pipeline fills)
         if (have && wave < SW) {
+            unsigned long long t_sc0 = 0;
+            if (timing) t_sc0 = clock64();   // diagnostic: the scorer wave's own time inside the shared region
             int r = tid;
 #if defined(SMX_EXP) && SMX_EXP == 5
             if (r < nr) { smx_op op; op.sample = -1; op.trim_start = 0; op.trim_end = lensC[r]; op.pool = -1; op.p1 = op.p2 = -1; op.barcode = -1;
@@ -1441,6 +1444,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     }
                 }
             }
+            if (timing) tacc[9] += clock64() - t_sc0;
         } else if (nxt < n_tiles) {
             // ---- phase 1 (of the NEXT tile): windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
             const int wid = have ? tid - 64 * SW : tid, nw = have ? NT - 64 * SW : NT;
@@ -1487,25 +1491,23 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     const int r = k / hc, c = k - r * hc;
                     const uint4 v = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (tail ? S : 0) + 16 * c);
                     const int L = lens[r0n + r];
-                    if (L >= S) {
-                        const unsigned w[4] = {v.x, v.y, v.z, v.w};
-                        const unsigned char *lt = lut + (tail ? 0 : 256);
-                        unsigned *dst = (unsigned *)(codes + (r * 2 + (tail ? 1 : 0)) * CS);
-                        unsigned any = 0;
+                    // ACGT fast path, four bases per dword without the LUT: (ch >> 1) & 3 maps A,C,T,G -> 0,1,2,3; swapping 2 and 3
+                    // gives the code, xor 3 the complement's code; one v_perm rebuilds the four letters from the codes and a
+                    // compare proves that the dword held nothing but upper-case ACGT (anything else: per-byte LUT path below)
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                    unsigned pk[4];
+                    bool acgt = L >= S;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            unsigned c0 = lt[w[q] & 0xFF], c1 = lt[(w[q] >> 8) & 0xFF], c2 = lt[(w[q] >> 16) & 0xFF], c3 = lt[w[q] >> 24];
-                            unsigned packed = tail ? (c0 | (c1 << 8) | (c2 << 16) | (c3 << 24))
-                                                   : (c3 | (c2 << 8) | (c1 << 16) | (c0 << 24));
-                            dst[tail ? 4 * c + q : S4 - 1 - (4 * c + q)] = packed;
-                            any |= packed;
-                        }
-                        if (any & 0x0C0C0C0Cu) {   // rare: a non-ACGT base in this chunk -> flag it for the prefilter rule
-                            const unsigned char *row = (const unsigned char *)dst;
-                            const int j0 = tail ? 16 * c : S - 16 * c - 16;
-                            for (int j = j0; j < j0 + 16; j++)
-                                if (row[j] > 3) atomicOr(&namask[(r * 2 + (tail ? 1 : 0)) * (MW + 1) + (j >> 5)], 1u << (j & 31));
-                        }
+                    for (int q = 0; q < 4; q++) {
+                        const unsigned x = (w[q] >> 1) & 0x03030303u;
+                        const unsigned y = x ^ ((x >> 1) & 0x01010101u);
+                        acgt = acgt && (__builtin_amdgcn_perm(0u, 0x54474341u, y) == w[q]);
+                        pk[q] = tail ? y : __builtin_amdgcn_perm(0u, y ^ 0x03030303u, 0x00010203u);
+                    }
+                    if (acgt) {
+                        unsigned *dst = (unsigned *)(codes + (r * 2 + (tail ? 1 : 0)) * CS);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) dst[tail ? 4 * c + q : S4 - 1 - (4 * c + q)] = pk[q];
                     } else {
                         encode_bytes(r, L, (tail ? S : 0) + 16 * c, v);
                     }

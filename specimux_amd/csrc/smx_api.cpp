@@ -123,7 +123,7 @@ struct smx_panel {
     void *d_blob = nullptr;
     int device = -1;
     int n_cu = 0;
-    int blocks_per_cu = 1;
+    int blocks_per_cu = 1, blocks_per_cu_slots = 1;   // resident workgroups per CU: lean / slots kernel
     std::mutex ws_mutex;                     // smx_batch_run is serialised per panel (one workspace)
     DevBuf ws[8];                            // windows, lens, ops, extra, n_extra, counts, hits, bdist
     DevBuf defer;                            // hit-table dumps of the reads deferred to the general scorer
@@ -287,7 +287,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     P->use64 = maxm > 32 ? 1 : 0;
     // tile size: largest R in {64, 32, ...} whose LDS image lets 4 workgroups share a CU's 160 KiB
     // (SMX_TILE_R / SMX_LDS_BUDGET override for tuning experiments)
-    size_t budget = 40 * 1024;   // 4 workgroups per CU (VGPR-limited to 4 waves/SIMD anyway)
+    size_t budget = 40 * 1024;   // 4 workgroups per CU; the k <= 3 bit-sliced kernel fits 5 (<= 96 VGPRs) when a tile needs <= 32 KiB
     if (const char *e = getenv("SMX_LDS_BUDGET")) budget = (size_t)atol(e);
     int rmax = 64;
     if (const char *e = getenv("SMX_TILE_R")) rmax = std::max(1, std::min(64, atoi(e)));
@@ -323,6 +323,12 @@ void smx_panel_destroy(smx_panel *P) {
             fprintf(stderr, " (inside the region: scorer wave %.1f%%, first encode wave %.1f%%)", tot ? 100.0 * sum[9] / tot : 0.0, tot ? 100.0 * sum[8] / tot : 0.0);
             fprintf(stderr, "\n");
             if (getenv("SMX_DEBUG")) {   // where did wave w of each workgroup land?  hist[w][simd]
+                {
+                    unsigned long long worked = 0, launches = 0;
+                    for (int b = 0; b < P->phase_grid; b++) { worked += h[(size_t)b * 16 + 14]; }
+                    fprintf(stderr, "[smx placement] workgroup-launches that processed at least one tile: %llu (grid %d)\n", worked, P->phase_grid);
+                    (void)launches;
+                }
                 int hist[4][4] = {{0}};
                 for (int b = 0; b < P->phase_grid; b++)
                     for (int w = 0; w < 4; w++) hist[w][(h[(size_t)b * 16 + 10 + w] >> 4) & 3]++;
@@ -402,20 +408,23 @@ static int ensure_device(smx_panel *P) {
     // persistent grid = exactly the resident workgroups (tiles are pulled from a queue): a workgroup that starts
     // after the queue has drained would only pay the panel staging and its one-time register spills
     {
+        const int bsv = !P->hp.bs_ok ? 0 : (P->hp.kidx < 4 ? 1 : 2);
         int occ = 0;
-        size_t worst = std::max(P->lds, P->lds_slots);
-        if (smx_query_occupancy(P->use64, worst, &occ) != 0 || occ < 1) occ = 4;
+        if (smx_query_occupancy(P->use64, bsv, P->lds, &occ) != 0 || occ < 1) occ = 4;
         P->blocks_per_cu = occ;
+        occ = 0;
+        if (smx_query_occupancy(P->use64, 0, P->lds_slots, &occ) != 0 || occ < 1) occ = 4;
+        P->blocks_per_cu_slots = occ;
     }
-    if (const char *e = getenv("SMX_BLOCKS_PER_CU")) P->blocks_per_cu = std::max(1, atoi(e));
+    if (const char *e = getenv("SMX_BLOCKS_PER_CU")) P->blocks_per_cu = P->blocks_per_cu_slots = std::max(1, atoi(e));
     if (getenv("SMX_DEBUG")) {
         int occ = -1;
-        (void)smx_query_occupancy(P->use64, P->lds, &occ);
+        (void)smx_query_occupancy(P->use64, !P->hp.bs_ok ? 0 : (P->hp.kidx < 4 ? 1 : 2), P->lds, &occ);
         fprintf(stderr, "[smx] lean R=%d lds=%zu | slots R=%d lds=%zu | occupancy API (lean): %d blocks/CU, grid multiplier %d, CUs %d\n",
                 P->R, P->lds, P->R_slots, P->lds_slots, occ, P->blocks_per_cu, P->n_cu);
     }
     if (getenv("SMX_PHASE_TIMING")) {
-        P->phase_grid = P->n_cu * P->blocks_per_cu;
+        P->phase_grid = P->n_cu * std::max(P->blocks_per_cu, P->blocks_per_cu_slots);
         HIP_TRY(hipMalloc((void **)&P->d_phase, (size_t)P->phase_grid * 16 * 8));
         HIP_TRY(hipMemset(P->d_phase, 0, (size_t)P->phase_grid * 16 * 8));
         h.dbg_phase = P->d_phase;
@@ -443,7 +452,7 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         if (de != hipSuccess) return fail(SMX_ERR_DEVICE, "deferred-read buffer: %s", hipGetErrorString(de));
     }
     uint32_t tiles = (n_reads + R - 1) / R;
-    int grid = (int)std::min<uint32_t>(tiles, (uint32_t)(P->n_cu * P->blocks_per_cu));
+    int grid = (int)std::min<uint32_t>(tiles, (uint32_t)(P->n_cu * (use_slots ? P->blocks_per_cu_slots : P->blocks_per_cu)));
     int e = smx_launch_demux(&P->hp, P->use64, R, grid, lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
                              extra_cap, d_n_extra, d_counts, d_hits, d_bdist, P->d_tile_counter, use_slots,
                              (unsigned char *)P->defer.p);

@@ -98,17 +98,17 @@ __device__ __forceinline__ BcGeom bc_geom(int L, int base, int bstart) {
 // LDS-resident per (read, primer, end) record.
 struct HitL {
     int tail_end;       // reference coord: max optimal end over all within-k barcodes (slots mode), valid if bbest >= 0
-    short pdist;        // -1 no primer match
     short nloc;
-    short bbest;        // -1 none, -2 not searched
     short ntied;
     short first_tied;   // local index in the primer's barcode list
+    signed char pdist;  // -1 no primer match (primers <= 64 nt)
+    signed char bbest;  // -1 none, -2 not searched (barcodes <= 32 nt)
     unsigned char jstar;   // window position of the first optimal primer end
     unsigned char fs_j;    // window position of its start (need_starts only)
     unsigned char flags;   // bit0: orientation vote, bit1: barcode search needed
-    unsigned char pad[3];
+    unsigned char pad;
 };
-static_assert(sizeof(HitL) == 20, "HitL layout");
+static_assert(sizeof(HitL) == 16, "HitL layout");
 
 #define SMX_MAX_EMIT 16
 // SMX_DEFER=1 builds the two-kernel variant: the hot kernel dumps the hit table of reads that need the general
@@ -163,9 +163,9 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     // at most 16 KiB worth of hits per round.  lean mode: per hit only (k+1) x MBW words of "barcodes seen at
     // distance d" bitmasks, at most 4 KiB per round.
     int dense = R * H;
-    int fit = slots ? (16 * 1024) / (t.G * 4) : (4 * 1024) / ((kidx + 1) * t.MBW * 4);
+    int fit = slots ? (16 * 1024) / (t.G * 4) : (3 * 1024) / ((kidx + 1) * t.MBW * 4);
     t.CAPH = dense < fit ? dense : (fit < 1 ? 1 : fit);
-    t.CAPE = t.CAPH + t.CAPH / 4 < 320 ? 320 : t.CAPH + t.CAPH / 4;   // >= 256 = max locations of one hit (progress)
+    t.CAPE = t.CAPH + t.CAPH / 4 < 256 ? 256 : t.CAPH + t.CAPH / 4;   // >= 256 = max locations of one hit (progress)
     if (cap_hits > 0 && cap_hits < t.CAPH) t.CAPH = cap_hits;          // test hook: many small rounds
     if (cap_ents >= S && cap_ents < t.CAPE) t.CAPE = cap_ents;         // (a hit has at most S locations)
     int o = 0;
@@ -179,24 +179,24 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.pmeta = o; o += npmeta * 4;
     o = (o + 15) & ~15;
     t.codes = o; o += R * 2 * t.CS;
-    t.namask = o; o += R * 2 * (MW + 1) * 4;   // per code row: bit j set = code[j] is not A/C/G/T (+1 guard word)
+    t.namask = o; o += R * 2 * MW * 4;         // per code row: bit j set = code[j] is not A/C/G/T
     t.lens = o;  o += 2 * R * 4;               // double-buffered: the next tile is encoded while this one is scored
-    t.ocnt = o;  o += 2 * R * 2 * 4;
+    t.ocnt = o;  o += 2 * R * 4;               // per read: forward votes | reverse votes << 16; double-buffered
     t.hits = o;  o += R * H * (int)sizeof(HitL);
-    t.masks = o; o += R * H * MW * 4;
     t.tiem = o;  o += R * H * t.MBW * 4;
-    // two time-shared regions: {slots | distance bitmasks} are dead once the scorer starts -> emission log;
-    // {location entries} are dead after the barcode scan -> staged result records
+    // time-shared regions: {location entries} are dead after the barcode scan -> staged result records;
+    // {primer end masks, scans, queue} are dead once the scorer starts -> its emission log
+    t.bres = t.dmask = o; o += slots ? t.CAPH * t.G * 4 : t.CAPH * (kidx + 1) * t.MBW * 4;
     {
-        int a = slots ? t.CAPH * t.G * 4 : t.CAPH * (kidx + 1) * t.MBW * 4, b = R * SMX_MAX_EMIT * 4;
-        t.bres = t.dmask = t.emit = o; o += a > b ? a : b;
         int c = t.CAPE * (int)sizeof(EntL), d = R * 32;
         o = (o + 15) & ~15;
         t.ents = t.opsL = o; o += c > d ? c : d;
     }
+    t.masks = t.emit = o; o += R * H * MW * 4;
     t.offsA = o; o += (R * H + 1) * 4;
     t.offsB = o; o += (R * H + 1) * 4;
     t.queue = o; o += ((R * H + 1) & ~1) * 2;
+    if (o < t.emit + R * SMX_MAX_EMIT * 4) o = t.emit + R * SMX_MAX_EMIT * 4;
     t.aggr = o;  o += 12 * 4;
     t.total = (o + 15) & ~15;
     return t;
@@ -851,7 +851,7 @@ __device__ inline void score_general(Emitter &E, int ori) {
 // BSV selects the barcode scan compiled into the kernel (one variant per kernel keeps their register allocations
 // apart): 0 = per-barcode bit-vector scan only, 1 = bit-sliced, k <= 3 (padded 7-row window), 2 = bit-sliced, k 4..7.
 template <typename PW, int NT, int BSV>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
-__global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
+__global__ __launch_bounds__(NT, BSV == 1 ? 5 : 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         const uint32_t r0 = have ? cur * R : 0u;
         const int nr = have ? (int)((n_reads - r0) < (uint32_t)R ? (n_reads - r0) : (uint32_t)R) : 0;
         const int nh = nr * H;
-        int *lensC = lensL + par * R, *ocntC = ocnt + par * 2 * R;
+        int *lensC = lensL + par * R, *ocntC = ocnt + par * R;
         if (timing) tacc[10] = clock64();
         if (have) {
         // ---- phase 2: primer scan, one lane per (read, primer, end)
@@ -1080,17 +1080,17 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             }
             HitL hl;
             hl.tail_end = -1;
-            hl.pdist = (short)(matched ? best : -1);
+            hl.pdist = (signed char)(matched ? best : -1);
             hl.nloc = (short)(matched ? cnt : 0);
             hl.bbest = -2; hl.ntied = 0; hl.first_tied = -1;
             hl.jstar = (unsigned char)jstar; hl.fs_j = (unsigned char)fs_j;
-            hl.flags = (unsigned char)(omatch ? 1 : 0); hl.pad[0] = hl.pad[1] = hl.pad[2] = 0;
+            hl.flags = (unsigned char)(omatch ? 1 : 0); hl.pad = 0;
             hits[item] = hl;
             if (omatch) {
                 // determine_orientation via A.6: fwd primer in A / rev primer in B vote "forward"
                 int dir = LP.pdir[p];
                 int vote_fwd = (dir == 0) ? (X == 0) : (X == 1);
-                atomicAdd(&ocntC[2 * r + (vote_fwd ? 0 : 1)], 1);
+                atomicAdd(&ocntC[r], vote_fwd ? 1 : 0x10000);
             }
         }
         __syncthreads();
@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         for (int item = tid; item < nh; item += NT) {
             int r = item / H, h = item - r * H, p = h >> 1, X = h & 1;
             int L = lensC[r];
-            int f = ocntC[2 * r], rv = ocntC[2 * r + 1];
+            int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
             int ori = 3;   // bit0: as-read candidates allowed, bit1: reverse-complement candidates allowed
             if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
             bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 int L = lensC[r];
                 EndGeom g = end_geom(L, S);
                 const unsigned *mrow = masks + (size_t)item * MW;
-                const unsigned *na = namask + (r * 2 + X) * (MW + 1);
+                const unsigned *na = namask + (r * 2 + X) * MW;
                 int e = offsA[item] - e_base, ord = 0;
                 for (int w = hl.jstar >> 5; w < MW; w++) {
                     unsigned word = mrow[w];
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                             if (!bg.pf_same || ncol < pfmin) ok = false;
                             else {   // any non-ACGT code among target[0 : pfmin) ?
                                 int wi = bg.tj0 >> 5, sh = bg.tj0 & 31;
-                                unsigned long long two = ((unsigned long long)na[wi + 1] << 32) | na[wi];
+                                unsigned long long two = ((unsigned long long)(wi + 1 < MW ? na[wi + 1] : 0u) << 32) | na[wi];
                                 if ((two >> sh) & ((1ull << pfmin) - 1ull)) ok = false;
                             }
                         }
@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                         }
                         if (nt) {
                             HitL &hl = hits[item];
-                            hl.bbest = (short)d; hl.ntied = (short)nt; hl.first_tied = (short)first;
+                            hl.bbest = (signed char)d; hl.ntied = (short)nt; hl.first_tied = (short)first;
                             for (int w = 0; w < MBW; w++) tiem[item * MBW + w] = dm[d * MBW + w];
                             break;
                         }
@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     int first = gm ? __ffsll((long long)gm) - 1 : 0;
                     if (in && sl == 0 && dmin != 255) {
                         HitL &hl = hits[item];
-                        hl.bbest = (short)dmin; hl.ntied = (short)__popcll(gm); hl.first_tied = (short)first;
+                        hl.bbest = (signed char)dmin; hl.ntied = (short)__popcll(gm); hl.first_tied = (short)first;
                         hl.tail_end = tail;
                         tiem[item * MBW] = (unsigned)gm;
                         if (MBW > 1) tiem[item * MBW + 1] = (unsigned)(gm >> 32);
@@ -1361,7 +1361,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                         tiem[item * MBW + (i >> 5)] |= 1u << (i & 31);
                     }
                 }
-                hl.bbest = (short)best; hl.ntied = (short)ntied; hl.first_tied = (short)first;
+                hl.bbest = (signed char)best; hl.ntied = (short)ntied; hl.first_tied = (short)first;
                 hl.tail_end = tail;
             }
             __syncthreads();
@@ -1371,8 +1371,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 
         }   // have
         // the encode target buffers: namask is OR-ed into, the next tile's orientation votes are counted up
-        for (int i = tid; i < R * 2 * (MW + 1); i += NT) namask[i] = 0;
-        for (int i = tid; i < 2 * R; i += NT) ocnt[(par ^ 1) * 2 * R + i] = 0;
+        for (int i = tid; i < R * 2 * MW; i += NT) namask[i] = 0;
+        for (int i = tid; i < R; i += NT) ocnt[(par ^ 1) * R + i] = 0;
         __syncthreads();
         const uint32_t nxt = (uint32_t)aggr[9];
         STAMP(0);
@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     ReadCtx c;
                     c.P = P; c.LP = LP; c.hits = hits + r * H; c.tiem = tiem + r * H * MBW; c.MBW = MBW; c.L = L; c.S = S;
                     c.g = end_geom(L, S);
-                    int f = ocntC[2 * r], rv = ocntC[2 * r + 1];
+                    int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
                     int ori = 3;
                     if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
                     Emitter E;
@@ -1468,14 +1468,14 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                             unsigned cd = lut[256 + ch];
                             int j = Sp - 1 - pos;
                             rowA[j] = (unsigned char)cd;
-                            if (cd > 3) atomicOr(&namask[(r * 2 + 0) * (MW + 1) + (j >> 5)], 1u << (j & 31));
+                            if (cd > 3) atomicOr(&namask[(r * 2 + 0) * MW + (j >> 5)], 1u << (j & 31));
                         }
                     } else if (pos < 2 * S) { // tail byte j -> B[j]
                         int j = pos - S;
                         if (j < Sp) {
                             unsigned cd = lut[ch];
                             rowB[j] = (unsigned char)cd;
-                            if (cd > 3) atomicOr(&namask[(r * 2 + 1) * (MW + 1) + (j >> 5)], 1u << (j & 31));
+                            if (cd > 3) atomicOr(&namask[(r * 2 + 1) * MW + (j >> 5)], 1u << (j & 31));
                         }
                     }
                 }
@@ -1556,6 +1556,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     }
     if (timing)
         for (int i = 0; i < 10; i++) P->dbg_phase[(size_t)blockIdx.x * 16 + i] += tacc[i];
+    if (timing) P->dbg_phase[(size_t)blockIdx.x * 16 + 14] += tacc[0] != 0 || tacc[1] != 0 ? 1 : 0;   // did this workgroup get any tile?
     if (P->dbg_phase != nullptr && (tid & 63) == 0)   // placement of this wave: HW_ID (simd, wave slot, cu, se)
         P->dbg_phase[(size_t)blockIdx.x * 16 + 10 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
 #undef STAMP
@@ -1688,10 +1689,12 @@ extern "C" size_t smx_deferred_rec_bytes(int NP, int maxB) {   // 0: the build k
     return SMX_DEFER ? (size_t)smx::deferred_rec_bytes(2 * NP, (maxB + 31) / 32) : 0;
 }
 
-extern "C" int smx_query_occupancy(int use64, size_t lds_bytes, int *blocks_per_cu) {
-    hipError_t e = use64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, smx::demux_kernel<unsigned long long, 256, 1>, 256, lds_bytes)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, smx::demux_kernel<unsigned, 256, 1>, 256, lds_bytes);
-    return (int)e;
+extern "C" int smx_query_occupancy(int use64, int bsv, size_t lds_bytes, int *blocks_per_cu) {
+    const void *fns[3] = {
+        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 0> : (const void *)smx::demux_kernel<unsigned, 256, 0>,
+        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 1> : (const void *)smx::demux_kernel<unsigned, 256, 1>,
+        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 2> : (const void *)smx::demux_kernel<unsigned, 256, 2>};
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fns[bsv < 0 || bsv > 2 ? 0 : bsv], 256, lds_bytes);
 }
 
 extern "C" int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SMX_ABI_VERSION 1
+#define SMX_ABI_VERSION 2
 
 typedef enum {
     SMX_OK = 0,
@@ -92,7 +92,8 @@ typedef struct smx_hit {
     int16_t bbest;        /* best barcode distance at this end, -1 none, -2 not searched (orientation pruned) */
     int16_t ntied;        /* barcodes tied at bbest */
     int16_t first_tied;   /* global barcode index of the first tied barcode (canonical order), -1 */
-    int16_t pad;
+    int16_t flags;        /* bit 0: this alignment votes in determine_orientation (demultiplex.py:602-638; differs from
+                             pdist >= 0 only for reads shorter than search_len - 1) */
 } smx_hit;
 
 /* Flattened panel; strings are concatenated ASCII with n+1 offsets. */
@@ -134,6 +135,7 @@ typedef struct smx_panel_desc {
     int32_t dereplicate;         /* SMX_DEREP_* */
     int32_t min_length;          /* -1 off */
     int32_t max_length;          /* -1 off */
+    int32_t want_starts;         /* 1: report first_start even when the trim mode does not need it (trace, --color) */
 } smx_panel_desc;
 
 typedef struct smx_panel smx_panel; /* opaque, immutable after create; holds host + device copies */

@@ -309,7 +309,8 @@ class ExactPrefilter:
 class Cand:
     """CandidateMatch (models.py:72-328)."""
 
-    def __init__(self, seq, oriented_reverse, b_len):
+    def __init__(self, seq, oriented_reverse, b_len, cid=None):
+        self.cid = cid                  # candidate_match_id (trace only)
         self.seq = seq                  # (id, bases, quals) in this candidate's orientation
         self.rev = oriented_reverse
         self.L = len(seq[1])
@@ -393,32 +394,79 @@ class Cand:
             self.p2m.shift(-start)
 
 
+# ------------------------------------------------------------------ trace events (trace.py:24-334)
+class Tracer:
+    """TraceLogger restated as an in-memory event list: rows are the TSV columns after the timestamp,
+    i.e. [worker_id, event_seq, sequence_id, event_type, *fields], every field already str()-ed the way
+    csv.writer would write it.  Verbosity rules: trace.py:318-334."""
+
+    def __init__(self, level=1, worker_id="main"):
+        self.level, self.worker_id, self.rows = level, worker_id, []
+
+    def seq_id(self, rec_id, num):  # trace.py:109-116
+        return f"{rec_id}#{num:08d}#{self.worker_id}"
+
+    def log(self, sid, etype, *fields):  # trace.py:96-107
+        self.rows.append([self.worker_id, str(len(self.rows) + 1), sid, etype] + [str(f) for f in fields])
+
+    @staticmethod
+    def info(c):  # trace.py:169-212 (_extract_match_info)
+        p1 = c.p1.name if c.p1 else "none"
+        p2 = c.p2.name if c.p2 else "none"
+        b1 = c.best_b1()[0] if c.best_b1() else "none"
+        b2 = c.best_b2()[0] if c.best_b2() else "none"
+        presence = "both" if c.b1 and c.b2 else "forward_only" if c.b1 else "reverse_only" if c.b2 else "none"
+        total = sum(d for d in (c.p1d(), c.p2d(), c.b1d(), c.b2d()) if d >= 0)
+        return c.cid or "unknown", p1, p2, b1, b2, presence, total, c.p1d(), c.p2d(), c.b1d(), c.b2d()
+
+    def primer_search(self, sid, name, direction, a, b, found, dist, pos):  # trace.py:318-325
+        if self.level >= 2 and (self.level >= 3 or found):
+            self.log(sid, "PRIMER_SEARCH", name, direction, a, b, str(found).lower(), dist, pos)
+
+    def barcode_search(self, sid, bc, btype, primer, a, b, found, dist, pos):  # trace.py:327-334
+        if self.level >= 3:
+            self.log(sid, "BARCODE_SEARCH", bc, btype, primer, a, b, str(found).lower(), dist, pos)
+
+
 # ------------------------------------------------------------------ the hot path
-def match_one_end(prefilter, cand, par, sequence, reversed_sequence, primer, which, hits=None):
+def match_one_end(prefilter, cand, par, sequence, reversed_sequence, primer, which, hits=None, tr=None, sid=None):
     """demultiplex.py:748-820"""
     L = len(sequence)
+    wdir = "forward" if which == 1 else "reverse"   # Primer.to_string / Barcode.to_string (constants.py:91-118)
+    if tr:
+        tr.primer_search(sid, primer.name, wdir, L - par.search_len, L, False, -1, -1)
     pm = align_seq(primer.primer_rc, sequence, par.max_dist_primers[primer.primer], L - par.search_len, L)
     if hits is not None:
         hits.append(("P", primer.name, "A" if reversed_sequence ^ cand.rev else "B", pm.dist, list(pm.locs)))
     if not pm.matched():
+        if tr:
+            tr.primer_search(sid, primer.name, wdir, L - par.search_len, L, False, -1, -1)
         return
+    pos = pm.locs[0][0] if pm.locs else -1   # read before set_primer: the reference logs the unreversed object
     cand.set_primer(pm, primer, reversed_sequence, which)
+    if tr:
+        tr.primer_search(sid, primer.name, wdir, L - par.search_len, L, True, pm.dist, pos)
     for b in primer.barcodes:
         b_rc = revcomp(b)
         best = None
         for loc in pm.locs:
             start = loc[1] + 1
+            if tr:
+                tr.barcode_search(sid, b, wdir, primer.name, start, L, False, -1, -1)
             if prefilter and not prefilter.match(b_rc, sequence[start:]):
                 continue
             bm = align_seq(b_rc, sequence, par.max_dist_index, start, L, E.SHW)
-            if bm.matched() and (best is None or bm.dist < best.dist):
-                best = bm
+            if bm.matched():
+                if tr:
+                    tr.barcode_search(sid, b, wdir, primer.name, start, L, True, bm.dist, bm.locs[0][0] if bm.locs else -1)
+                if best is None or bm.dist < best.dist:
+                    best = bm
         if best is not None:
             cand.add_barcode(best, b, reversed_sequence, which)
 
 
-def determine_orientation(par, s, rs, fwd, rev):
-    """demultiplex.py:602-638 -> 'F', 'R' or 'U'"""
+def determine_orientation(par, s, rs, fwd, rev, counts=False):
+    """demultiplex.py:602-638 -> 'F', 'R' or 'U' (with counts=True: (orientation, fwd_score, rev_score))"""
     f = r = 0
     for p in fwd:
         k = par.max_dist_primers[p.primer]
@@ -428,11 +476,8 @@ def determine_orientation(par, s, rs, fwd, rev):
         k = par.max_dist_primers[p.primer]
         f += align_seq(p.primer, rs, k, 0, par.search_len).matched()
         r += align_seq(p.primer, s, k, 0, par.search_len).matched()
-    if f > 0 and r == 0:
-        return "F"
-    if r > 0 and f == 0:
-        return "R"
-    return "U"
+    o = "F" if f > 0 and r == 0 else "R" if r > 0 and f == 0 else "U"
+    return (o, f, r) if counts else o
 
 
 def pool_from_primers(p1, p2):  # demultiplex.py:640-665
@@ -446,26 +491,49 @@ def pool_from_primers(p1, p2):  # demultiplex.py:640-665
     return None
 
 
-def find_candidates(prefilter, par, panel, seq, rseq):
+_ORI_NAME = {"F": "forward", "R": "reverse", "U": "unknown"}   # Orientation.to_string (constants.py:121-129)
+
+
+def find_candidates(prefilter, par, panel, seq, rseq, tr=None, sid=None):
     """demultiplex.py:668-746"""
     s, rs = seq[1], rseq[1]
-    ori = determine_orientation(par, s, rs, panel.get_primers(FWD), panel.get_primers(REV)) if par.preorient else "U"
+    if par.preorient:
+        ori, fs, rv = determine_orientation(par, s, rs, panel.get_primers(FWD), panel.get_primers(REV), counts=True)
+        if tr:
+            conf = abs(fs - rv) / (fs + rv) if fs + rv > 0 else 0.0
+            tr.log(sid, "ORIENTATION_DETECTED", _ORI_NAME[ori], fs, rv, f"{conf:.3f}")
+    else:
+        ori = "U"
+        if tr:
+            tr.log(sid, "ORIENTATION_DETECTED", "unknown", 0, 0, f"{0.0:.3f}")
     out = []
+
+    def logged(c, pool, used):   # trace.py:132-167
+        if not tr:
+            return
+        cid, p1, p2, b1, b2, _pres, _tot, p1d, p2d, b1d, b2d = Tracer.info(c)
+        mtype = "both" if c.p1m and c.p2m else "forward_only" if c.p1m else "reverse_only"
+        tr.log(sid, "PRIMER_MATCHED", cid, mtype, p1, p2, p1d, p2d, pool or "none", used)
+        btype = "both" if c.b1 and c.b2 else "forward_only" if c.b1 else "reverse_only" if c.b2 else "none"
+        tr.log(sid, "BARCODE_MATCHED", cid, btype, b1, b2, b1d, b2d, p1, p2)
+
     for fp in panel.get_primers(FWD):
         for rp in panel.get_paired(fp.primer):
             if ori in "FU":
-                c = Cand(seq, False, panel.b_length)
-                match_one_end(prefilter, c, par, rs, True, fp, 1)
-                match_one_end(prefilter, c, par, s, False, rp, 2)
+                c = Cand(seq, False, panel.b_length, f"{sid}_match_{len(out)}")
+                match_one_end(prefilter, c, par, rs, True, fp, 1, tr=tr, sid=sid)
+                match_one_end(prefilter, c, par, s, False, rp, 2, tr=tr, sid=sid)
                 if c.p1m or c.p2m:
                     c.pool = pool_from_primers(fp, rp)
+                    logged(c, c.pool, "as_is")
                     out.append(c)
             if ori in "RU":
-                c = Cand(rseq, True, panel.b_length)
-                match_one_end(prefilter, c, par, s, True, fp, 1)
-                match_one_end(prefilter, c, par, rs, False, rp, 2)
+                c = Cand(rseq, True, panel.b_length, f"{sid}_match_{len(out)}")
+                match_one_end(prefilter, c, par, s, True, fp, 1, tr=tr, sid=sid)
+                match_one_end(prefilter, c, par, rs, False, rp, 2, tr=tr, sid=sid)
                 if c.p1m or c.p2m:
                     c.pool = pool_from_primers(fp, rp)
+                    logged(c, c.pool, "reverse_complement")
                     out.append(c)
     return out
 
@@ -485,8 +553,16 @@ def score(c):  # demultiplex.py:226-236
     return 0
 
 
-def select_best(cands):  # demultiplex.py:216-259 (stable)
+def select_best(cands, tr=None, sid=None):  # demultiplex.py:216-259 (stable)
     best = max(score(c) for c in cands)
+    if tr:
+        for c in cands:   # trace.py:214-222
+            cid, p1, p2, b1, b2, pres, tot = Tracer.info(c)[:7]
+            tr.log(sid, "MATCH_SCORED", cid, p1, p2, b1, b2, tot, pres, f"{float(score(c)):.3f}")
+        for c in sorted(cands, key=score, reverse=True):   # stable: the reference sorts before discarding
+            if score(c) < best:
+                cid, p1, p2, b1, b2 = Tracer.info(c)[:5]
+                tr.log(sid, "MATCH_DISCARDED", cid, p1, p2, b1, b2, float(score(c)), "lower_score")
     return [c for c in cands if score(c) == best]
 
 
@@ -494,7 +570,7 @@ def _fidx(p, missing):
     return p.file_index if p else missing
 
 
-def derep_partial(ms):  # demultiplex.py:396-477
+def derep_partial(ms, tr=None, sid=None):  # demultiplex.py:396-477
     groups = OrderedDict()
     for m in ms:
         if m.b1 and not m.b2:
@@ -506,17 +582,21 @@ def derep_partial(ms):  # demultiplex.py:396-477
         for b in bcs:
             groups.setdefault((d, b), []).append(m)
     out = []
-    for (d, _b), g in groups.items():
+    for (d, b), g in groups.items():
         def key(m):
             cnt = (1 if m.p1 else 0) + (1 if m.p2 else 0)
             pd = (m.p1d() if m.p1 else 0) + (m.p2d() if m.p2 else 0)
             fi = _fidx(m.p1, 0) + _fidx(m.p2, 0)
             return (m.b1d() if d == "forward" else m.b2d(), -cnt, pd, fi)
-        out.append(sorted(g, key=key)[0])
+        win = sorted(g, key=key)[0]
+        out.append(win)
+        if tr:   # trace.py:283-297
+            k = key(win)
+            tr.log(sid, "DEREPLICATE_PARTIAL_SELECTED", d, b, len(g), k[0], -k[1], k[2], k[3])
     return out
 
 
-def derep_unknown(ms):  # demultiplex.py:480-538
+def derep_unknown(ms, tr=None, sid=None):  # demultiplex.py:480-538
     if not ms:
         return []
 
@@ -524,10 +604,14 @@ def derep_unknown(ms):  # demultiplex.py:480-538
         cnt = (1 if m.p1 else 0) + (1 if m.p2 else 0)
         pd = (m.p1d() if m.p1 else 0) + (m.p2d() if m.p2 else 0)
         return (-cnt, pd, _fidx(m.p1, 999) + _fidx(m.p2, 999))
-    return [sorted(ms, key=key)[0]]
+    win = sorted(ms, key=key)[0]
+    if tr and len(ms) > 1:   # demultiplex.py:533-536
+        k = key(win)
+        tr.log(sid, "DEREPLICATE_UNKNOWN_SELECTED", len(ms), -k[0], k[1], k[2])
+    return [win]
 
 
-def dereplicate(ms, panel):  # demultiplex.py:262-393
+def dereplicate(ms, panel, tr=None, sid=None):  # demultiplex.py:262-393
     expanded = []
     for m in ms:
         if not m.full():
@@ -536,68 +620,87 @@ def dereplicate(ms, panel):  # demultiplex.py:262-393
         found = False
         for b1 in m.best_b1():
             for b2 in m.best_b2():
-                sid = panel.specimen_for_exact(b1, b2, m.p1, m.p2)
-                if sid:
-                    expanded.append((m, sid, b1, b2, m.b1d(), m.b2d()))
+                spec = panel.specimen_for_exact(b1, b2, m.p1, m.p2)
+                if spec:
+                    expanded.append((m, spec, b1, b2, m.b1d(), m.b2d()))
                     found = True
         if not found:
             expanded.append((m, None, None, None, 999, 999))
+    if tr:
+        tr.log(sid, "DEREPLICATE_EXPANDED", len(ms), len(expanded))
     groups = OrderedDict()
     for e in expanded:
         groups.setdefault(e[1], []).append(e)
     res = []
-    for sid, g in groups.items():
-        if sid is None:
+    for spec, g in groups.items():
+        if spec is None:
             one = [e[0] for e in g if bool(e[0].b1) != bool(e[0].b2)]
             none = [e[0] for e in g if not e[0].b1 and not e[0].b2]
             both = [e[0] for e in g if e[0].b1 and e[0].b2]
-            res += [(m, None, None, None) for m in derep_partial(one)] if one else []
-            res += [(m, None, None, None) for m in derep_unknown(none)] if none else []
+            res += [(m, None, None, None) for m in derep_partial(one, tr, sid)] if one else []
+            res += [(m, None, None, None) for m in derep_unknown(none, tr, sid)] if none else []
             res += [(m, None, None, None) for m in both]
             continue
-        g = sorted(g, key=lambda e: (e[4] + e[5], e[0].p1d() + e[0].p2d(), _fidx(e[0].p1, 999) + _fidx(e[0].p2, 999)))
-        res.append((g[0][0], sid, g[0][2], g[0][3]))
+
+        def key(e):
+            return (e[4] + e[5], e[0].p1d() + e[0].p2d(), _fidx(e[0].p1, 999) + _fidx(e[0].p2, 999))
+        g = sorted(g, key=key)
+        res.append((g[0][0], spec, g[0][2], g[0][3]))
+        if tr:   # demultiplex.py:385-391
+            k = key(g[0])
+            tr.log(sid, "DEREPLICATE_SELECTED", spec, len(g), k[0], k[1], k[2])
     return res
 
 
-def resolve_specimen(m, panel):  # demultiplex.py:541-598
+_RTYPE_NAME = {R_FULL: "full_match", R_PFWD: "partial_forward", R_PREV: "partial_reverse", R_MULTI: "multiple_specimens",
+               R_UNKNOWN: "unknown", R_DEREP: "dereplicated_full"}   # ResolutionType.to_string (constants.py:62-75)
+
+
+def resolve_specimen(m, panel, tr=None, sid=None):  # demultiplex.py:541-598
+    spec, rt = UNKNOWN, R_UNKNOWN
     if m.full():
         ids = panel.specimens_for(m.best_b1(), m.best_b2(), m.p1, m.p2)
         if len(ids) > 1:
             m.pool = panel.specimen_pool(ids[0])
-            return ids[0], R_MULTI
-        if len(ids) == 1:
+            spec, rt = ids[0], R_MULTI
+        elif len(ids) == 1:
             m.pool = panel.specimen_pool(ids[0])
-            return ids[0], R_FULL
-        return UNKNOWN, R_UNKNOWN
-    b1s, b2s = m.best_b1(), m.best_b2()
-    if m.b1 and not m.b2 and len(b1s) == 1:
-        return "barcode_fwd_" + b1s[0], R_PFWD
-    if m.b2 and not m.b1 and len(b2s) == 1:
-        return "barcode_rev_" + b2s[0], R_PREV
-    return UNKNOWN, R_UNKNOWN
+            spec, rt = ids[0], R_FULL
+    else:
+        b1s, b2s = m.best_b1(), m.best_b2()
+        if m.b1 and not m.b2 and len(b1s) == 1:
+            spec, rt = "barcode_fwd_" + b1s[0], R_PFWD
+        elif m.b2 and not m.b1 and len(b2s) == 1:
+            spec, rt = "barcode_rev_" + b2s[0], R_PREV
+    if tr:   # demultiplex.py:592-594, trace.py:233-239
+        _cid, p1, p2, b1, b2 = Tracer.info(m)[:5]
+        tr.log(sid, "SPECIMEN_RESOLVED", spec, _RTYPE_NAME[rt], m.pool or "none", p1, p2, b1, b2)
+    return spec, rt
 
 
 class Op:
     """WriteOperation (models.py:341-357), only the fields that reach a file/stdout."""
     __slots__ = ("sample_id", "seq_id", "code", "sequence", "quality", "pool", "p1", "p2", "rtype",
-                 "p1_loc", "p2_loc", "b1_loc", "b2_loc", "trim", "reverse")
+                 "p1_loc", "p2_loc", "b1_loc", "b2_loc", "trim", "reverse", "trace_id")
 
     def key(self):
         return (self.seq_id, self.sample_id, self.code, self.pool, self.p1, self.p2, self.rtype,
                 self.sequence, self.quality)
 
 
-def make_op(sample_id, par, m, rtype):  # demultiplex.py:30-103
-    sid, bases, quals = m.seq
+def make_op(sample_id, par, m, rtype, tr=None, sid=None):  # demultiplex.py:30-103
+    rid, bases, quals = m.seq
     op = Op()
-    op.seq_id, op.code = sid, m.code()
+    op.seq_id, op.code, op.trace_id = rid, m.code(), sid
     op.trim, op.reverse = (0, len(bases)), m.rev     # extent actually cut from the oriented read (tests only)
     fallback = False
     if par.trim != "none":
         s, e = m.extent(par.trim)
         if s >= e:  # Q12: would trim to nothing -> untrimmed record to unknown/unknown/unknown-unknown
             fallback = True
+            if tr:   # demultiplex.py:50-54
+                tr.log(sid, "SEQUENCE_TRIM_EMPTY", par.trim, s, e, len(bases), m.p1.name if m.p1 else "unknown",
+                       m.p2.name if m.p2 else "unknown")
         else:
             bases, quals = bases[s:e], quals[s:e]
             op.trim = (s, e)
@@ -618,43 +721,60 @@ def make_op(sample_id, par, m, rtype):  # demultiplex.py:30-103
     return op
 
 
-def process_sequences(records, par, panel, prefilter="auto"):
+def process_sequences(records, par, panel, prefilter="auto", tr=None, record_offset=0):
     """demultiplex.py:108-212.  records: iterable of (id, bases, quality_string).
-    Returns (ops, total, matched)."""
+    Returns (ops, total, matched).  tr: optional Tracer collecting the reference's trace events."""
     if prefilter == "auto":
         prefilter = make_prefilter(panel, par) if par.prefilter else None
     ops, total, matched = [], 0, 0
-    for rec in records:
+    for idx, rec in enumerate(records):
         total += 1
         L = len(rec[1])
+        sid = None
+        if tr:
+            sid = tr.seq_id(rec[0], record_offset + idx)
+            tr.log(sid, "SEQUENCE_RECEIVED", L, rec[0])
         if par.min_length != -1 and L < par.min_length:
+            if tr:
+                tr.log(sid, "SEQUENCE_FILTERED", L, "too_short")
             continue
         if par.max_length != -1 and L > par.max_length:
+            if tr:
+                tr.log(sid, "SEQUENCE_FILTERED", L, "too_long")
             continue
         rrec = (rec[0], revcomp(rec[1]), rec[2][::-1])
-        cands = find_candidates(prefilter, par, panel, rec, rrec)
+        cands = find_candidates(prefilter, par, panel, rec, rrec, tr, sid)
         if not cands:
-            ops.append(make_op(UNKNOWN, par, Cand(rec, False, panel.b_length), R_UNKNOWN))
+            if tr:
+                tr.log(sid, "NO_MATCH_FOUND", "primer_search", "No primer matches found")
+            ops.append(make_op(UNKNOWN, par, Cand(rec, False, panel.b_length), R_UNKNOWN, tr, sid))
             continue
-        best = select_best(cands)
+        best = select_best(cands, tr, sid)
         full = False
         if par.dereplicate == "best":
-            for m, sid, _b1, _b2 in dereplicate(best, panel):
-                if sid is not None:
-                    m.pool = panel.specimen_pool(sid)
-                    ops.append(make_op(sid, par, m, R_DEREP))
+            for m, spec, _b1, _b2 in dereplicate(best, panel, tr, sid):
+                if spec is not None:
+                    m.pool = panel.specimen_pool(spec)
+                    ops.append(make_op(spec, par, m, R_DEREP, tr, sid))
                     full = True
                 else:
-                    fid, rt = resolve_specimen(m, panel)
-                    ops.append(make_op(fid, par, m, rt))
+                    fid, rt = resolve_specimen(m, panel, tr, sid)
+                    ops.append(make_op(fid, par, m, rt, tr, sid))
                     full = full or rt in (R_FULL, R_DEREP)
         else:
             for m in best:
-                fid, rt = resolve_specimen(m, panel)
-                ops.append(make_op(fid, par, m, rt))
+                fid, rt = resolve_specimen(m, panel, tr, sid)
+                ops.append(make_op(fid, par, m, rt, tr, sid))
                 full = full or rt in (R_FULL, R_DEREP)
         matched += 1 if full else 0
     return ops, total, matched
+
+
+def trace_outputs(tr, ops, prefix="", fastq=True):
+    """The SEQUENCE_OUTPUT events written when a batch's operations reach the OutputManager
+    (io_utils.py:221-233): relative path of the primary file, primer pair "p1-p2"."""
+    for op in ops:
+        tr.log(op.trace_id, "SEQUENCE_OUTPUT", op.sample_id, op.pool, f"{op.p1}-{op.p2}", op_path(op, prefix, fastq)[0])
 
 
 def make_prefilter(panel, par):

@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMX_LIB") or os.path.join(_HERE, "libsmx.so")   # SMX_LIB: A/B builds (tools/tune.sh)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_DEVICE, ERR_OVERFLOW = 0, -1, -2, -3, -4
 TRIM = {"none": 0, "tails": 1, "barcodes": 2, "primers": 3}
 DEREP = {"none": 0, "best": 1}
@@ -23,7 +23,7 @@ OP_DTYPE = np.dtype([("sample", "<i4"), ("trim_start", "<i4"), ("trim_end", "<i4
                      ("p1", "<i2"), ("p2", "<i2"), ("barcode", "<i2"), ("dist", "i1", (4,)), ("rtype", "u1"),
                      ("flags", "u1"), ("n_ops", "<u2"), ("read", "<u4")])
 HIT_DTYPE = np.dtype([("first_start", "<i4"), ("first_end", "<i4"), ("tail_end", "<i4"), ("pdist", "<i2"),
-                      ("nloc", "<i2"), ("bbest", "<i2"), ("ntied", "<i2"), ("first_tied", "<i2"), ("pad", "<i2")])
+                      ("nloc", "<i2"), ("bbest", "<i2"), ("ntied", "<i2"), ("first_tied", "<i2"), ("flags", "<i2")])
 assert OP_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 24
 
 
@@ -38,7 +38,8 @@ class PanelDesc(C.Structure):
                 ("spec_p2mask", C.c_void_p), ("spec_pool", C.c_void_p),
                 ("k_index", C.c_int32), ("search_len", C.c_int32), ("barcode_len_max", C.c_int32),
                 ("prefilter_min_len", C.c_int32), ("preorient", C.c_int32), ("trim", C.c_int32),
-                ("dereplicate", C.c_int32), ("min_length", C.c_int32), ("max_length", C.c_int32)]
+                ("dereplicate", C.c_int32), ("min_length", C.c_int32), ("max_length", C.c_int32),
+                ("want_starts", C.c_int32)]
 
 
 # every symbol include/smx.h declares: (name, restype, argtypes)

@@ -184,7 +184,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     h.derep = d->dereplicate;
     h.minlen = d->min_length;
     h.maxlen = d->max_length;
-    h.need_starts = (d->trim == SMX_TRIM_PRIMERS || d->trim == SMX_TRIM_TAILS) ? 1 : 0;
+    h.need_starts = (d->trim == SMX_TRIM_PRIMERS || d->trim == SMX_TRIM_TAILS || d->want_starts) ? 1 : 0;
 
     std::string bad;
     std::vector<unsigned long long> ppeq(NP * 16), prpeq(NP * 16);

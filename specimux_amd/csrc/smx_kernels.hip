@@ -1543,7 +1543,7 @@ __global__ __launch_bounds__(NT, BSV == 1 ? 5 : 4) void demux_kernel(DevPanel Pv
                 o.bbest = hl.bbest; o.ntied = hl.ntied;
                 o.first_tied = (short)((hl.bbest >= 0) ? LP.pbc[LP.pbc_off[(item - r * H) >> 1] + hl.first_tied] : -1);
                 o.tail_end = hl.bbest >= 0 ? hl.tail_end : -1;
-                o.pad = 0;
+                o.flags = (int16_t)(hl.flags & 1);
                 dbg_hits[(size_t)(r0 + r) * H + (item - r * H)] = o;
             }
         }

@@ -29,16 +29,17 @@ def _prefilter_enabled(prefilter) -> bool:
         "PassthroughPrefilter() or specimux_amd.bloom_filter.BloomPrefilter")
 
 
-def compiled_panel(specimens, parameters, args, prefilter) -> CompiledPanel:
+def compiled_panel(specimens, parameters, args, prefilter, want_starts=False) -> CompiledPanel:
     """One CompiledPanel per distinct (panel, thresholds, flags); cached on the Specimens object."""
     key = (parameters.max_dist_index, parameters.search_len, parameters.preorient,
            tuple(sorted(parameters.max_dist_primers.items())), getattr(args, "trim", TrimMode.BARCODES),
            getattr(args, "dereplicate", MultipleMatchStrategy.BEST), _prefilter_enabled(prefilter),
-           getattr(args, "min_length", -1), getattr(args, "max_length", -1), len(specimens._specimens))
+           getattr(args, "min_length", -1), getattr(args, "max_length", -1), len(specimens._specimens),
+           bool(want_starts))
     cache = specimens.__dict__.setdefault("_smx_panels", {})
     if key not in cache:
         cache[key] = CompiledPanel(specimens, parameters, trim=key[4], dereplicate=key[5], prefilter=key[6],
-                                   min_length=key[7], max_length=key[8])
+                                   min_length=key[7], max_length=key[8], want_starts=key[10])
     return cache[key]
 
 
@@ -86,14 +87,25 @@ def op_names(panel: CompiledPanel, rec):
 
 def process_sequences(seq_records, parameters, specimens, args, prefilter, trace_logger=None,
                       record_offset: int = 0) -> Tuple[List[WriteOperation], int, int]:
-    """Demultiplex one batch of reads on the GPU; see the module docstring."""
-    if trace_logger is not None:
-        raise NotImplementedError("trace logging (-d) is not available on the GPU path yet")
+    """Demultiplex one batch of reads on the GPU; see the module docstring.  With a trace_logger the kernel also
+    returns the hit tables it scored from and trace.py replays the reference's events from them."""
     seq_records = list(seq_records)
-    panel = compiled_panel(specimens, parameters, args, prefilter)
+    tracing = trace_logger is not None and getattr(trace_logger, "enabled", True)
+    panel = compiled_panel(specimens, parameters, args, prefilter, want_starts=tracing)
     bases, offsets, seqs = concat_records(seq_records)
     windows, lens = panel.pack_windows(bases, offsets)
-    ops, extra, counts = panel.run(windows, lens)
+    trace_ids = {}
+    if tracing:
+        from . import trace as _trace
+        ops, extra, counts, hits, bdist = panel.run(windows, lens, want_hits=True)
+        replayer = panel.__dict__.get("_replayer")
+        if replayer is None:
+            replayer = panel.__dict__["_replayer"] = _trace.BatchReplayer(panel, parameters, specimens, args,
+                                                                          _prefilter_enabled(prefilter))
+        trace_ids = _trace.replay_batch(trace_logger, replayer, seq_records, seqs, ops, extra, hits, bdist, op_names,
+                                        record_offset)
+    else:
+        ops, extra, counts = panel.run(windows, lens)
     write_ops: List[WriteOperation] = []
     rc_cache = {}
     for i, rec in order_ops(ops, extra):
@@ -117,5 +129,6 @@ def process_sequences(seq_records, parameters, specimens, args, prefilter, trace
         write_ops.append(WriteOperation(
             sample_id=sample, seq_id=record.id, distance_code=code, sequence=s, quality_sequence=q,
             quality_scores=[ord(c) - 33 for c in q], p1_location=None, p2_location=None, b1_location=None,
-            b2_location=None, primer_pool=pool, p1_name=p1, p2_name=p2, resolution_type=rtype))
+            b2_location=None, primer_pool=pool, p1_name=p1, p2_name=p2, resolution_type=rtype,
+            trace_sequence_id=trace_ids.get(i)))
     return write_ops, len(seq_records), int(counts[_lib.CNT_MATCHED])

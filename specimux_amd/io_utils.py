@@ -230,8 +230,13 @@ class OutputManager:
 
     def write_sequence(self, write_op: WriteOperation, trace_logger=None):
         text = self.record_text(write_op)
-        self.write(self._make_filename(write_op.sample_id, write_op.primer_pool, write_op.p1_name, write_op.p2_name,
-                                       write_op.resolution_type), text)
+        filename = self._make_filename(write_op.sample_id, write_op.primer_pool, write_op.p1_name, write_op.p2_name,
+                                       write_op.resolution_type)
+        if trace_logger:   # io_utils.py:227-233: the path relative to the output directory
+            trace_logger.log_sequence_output(write_op.trace_sequence_id, write_op.sample_id, write_op.primer_pool,
+                                             f"{write_op.p1_name}-{write_op.p2_name}",
+                                             os.path.relpath(filename, self.output_dir))
+        self.write(filename, text)
         if write_op.resolution_type.is_full_match():   # pool-level aggregate (io_utils.py:256-268)
             ext = ".fastq" if self.is_fastq else ".fasta"
             self.write(os.path.join(self.output_dir, "full", write_op.primer_pool,

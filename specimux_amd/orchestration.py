@@ -5,6 +5,7 @@ specimux (:153, :458) stream the read file in large batches through process-loca
 of a multiprocessing.Pool of 1000-read batches.  Same log lines (`Processed N sequences, match rate: X%`,
 `Elapsed time`), same output tree."""
 import itertools
+from datetime import datetime
 import logging
 import math
 import os
@@ -251,9 +252,21 @@ def _run_records(args, to_files: bool):
         if manager:
             manager.__enter__()
         for batch in iter_batches(seq_records, GPU_BATCH_READS, args.num_seqs, args.num_seqs < 0):
-            ops, n, m = process_sequences(batch, parameters, specimens, args, prefilter, None, total)
-            for op in ops:
-                output_write_operation(op, manager, args, None)
+            # one trace file per batch, like the reference's single-process loop (orchestration.py:501-521);
+            # with -F the reference's files carry the worker's name: the GPU path has one "worker"
+            trace_logger = None
+            if getattr(args, "diagnostics", None):
+                from .trace import TraceLogger
+                trace_logger = TraceLogger(enabled=True, verbosity=args.diagnostics, output_dir=args.output_dir,
+                                           worker_id="worker_1" if to_files else "main",
+                                           start_timestamp=datetime.now().strftime("%Y%m%d_%H%M%S"))
+            try:
+                ops, n, m = process_sequences(batch, parameters, specimens, args, prefilter, trace_logger, total)
+                for op in ops:
+                    output_write_operation(op, manager, args, trace_logger)
+            finally:
+                if trace_logger:
+                    trace_logger.close()
             total += n
             matched += m
     finally:
@@ -269,7 +282,9 @@ def specimux_mp(args):
     """File-output entry (`-F`).  The reference forks a worker pool here; the GPU path needs no host
     parallelism for the matching itself."""
     if getattr(args, "diagnostics", None):
-        raise NotImplementedError("trace logging (-d) is not available on the GPU path yet")
+        # trace events are attached to record objects: the record path (Python parser) carries them
+        _run_records(args, to_files=True)
+        return
     _run_native(args)
 
 

@@ -20,7 +20,7 @@ class CompiledPanel:
     """Owns the smx_panel handle plus the index -> name tables needed to print results."""
 
     def __init__(self, specimens, parameters, trim="barcodes", dereplicate="best", prefilter=True,
-                 min_length=-1, max_length=-1):
+                 min_length=-1, max_length=-1, want_starts=False):
         lib = _lib.load()
         self._lib = lib
         self.handle = None
@@ -122,6 +122,7 @@ class CompiledPanel:
         d.trim = _lib.TRIM[trim]
         d.dereplicate = _lib.DEREP[dereplicate]
         d.min_length, d.max_length = int(min_length), int(max_length)
+        d.want_starts = 1 if want_starts else 0
         self.desc = d
         self.pairs = pairs
         self.search_len = int(parameters.search_len)

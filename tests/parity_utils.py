@@ -76,6 +76,40 @@ class Both:
                                  f"  oracle: {[k[1:7] + (len(k[7]),) for k in by_e.get(rid, [])]}\n  seq: {seq}")
         return got
 
+    # ------------------------------------------------------------------ trace events (-d)
+    def product_trace(self, reads, level, out_dir, worker_id="main", record_offset=0):
+        """Rows of the TSV the product writes for this batch, without the timestamp column."""
+        import csv
+        from specimux_amd.demultiplex import process_sequences
+        from specimux_amd.io_utils import OutputManager, SeqRecord, output_write_operation
+        from specimux_amd.trace import TraceLogger
+        recs = [SeqRecord(s, rid, rid, q) for rid, s, q in reads]
+        self.args.output_dir, self.args.output_to_files, self.args.output_file_prefix = str(out_dir), True, ""
+        tl = TraceLogger(True, level, str(out_dir), worker_id, "20260101_000000")
+        ops, _t, _m = process_sequences(recs, self.parameters, self.specimens, self.args, self.prefilter, tl, record_offset)
+        with OutputManager(str(out_dir), "", True) as om:
+            for op in ops:
+                output_write_operation(op, om, self.args, tl)
+        tl.close()
+        with open(tl.filepath, newline="") as fh:
+            rows = list(csv.reader(fh, delimiter="\t"))
+        assert rows[0] == ["timestamp", "worker_id", "event_seq", "sequence_id", "event_type"]
+        return [r[1:] for r in rows[1:]]
+
+    def oracle_trace(self, reads, level, worker_id="main", record_offset=0):
+        tr = O.Tracer(level, worker_id)
+        ops, _t, _m = O.process_sequences(reads, self.opar, self.opanel, tr=tr, record_offset=record_offset)
+        O.trace_outputs(tr, ops)
+        return tr.rows
+
+    def assert_trace_equal(self, reads, level, out_dir, label=""):
+        got = self.product_trace(reads, level, out_dir)
+        exp = self.oracle_trace(reads, level)
+        for i, (g, e) in enumerate(zip(got, exp)):
+            assert g == e, f"{label} level {level}: event {i + 1} differs\n  gpu   : {g}\n  oracle: {e}"
+        assert len(got) == len(exp), f"{label} level {level}: {len(got)} events != oracle {len(exp)}"
+        return len(got)
+
     # ------------------------------------------------------------------ hit tables
     def assert_hits_equal(self, reads, label=""):
         from specimux_amd.demultiplex import compiled_panel, concat_records

@@ -94,6 +94,24 @@ def test_golden_tree_equals_reference_expected_output(lib, tmp_path):
     assert not (out / "partial" / "unknown").exists()   # empty directories are pruned
 
 
+def test_reference_integration_command_with_trace(lib, tmp_path):
+    """tests/test_integration.py:75-114 verbatim: `-F -O out -d` must produce the expected tree AND a trace
+    directory (`_validate_output_structure` :141-148); the trace file carries one SEQUENCE_OUTPUT per record."""
+    import csv
+    from specimux_amd import cli
+    out = tmp_path / "out"
+    cli.main(["specimux", P, S, f"{GOLDEN}/sequences.fastq", "-F", "-O", str(out), "-d"])
+    assert read_expected_tree(str(out)) == read_expected_tree(f"{GOLDEN}/expected_output")
+    files = sorted((out / "trace").glob("specimux_trace_*_worker_1.tsv"))
+    assert len(files) == 1
+    rows = list(csv.reader(open(files[0], newline=""), delimiter="\t"))
+    assert rows[0] == ["timestamp", "worker_id", "event_seq", "sequence_id", "event_type"]
+    kinds = [r[4] for r in rows[1:]]
+    assert kinds.count("SEQUENCE_RECEIVED") == 40 and kinds.count("SEQUENCE_OUTPUT") == 40
+    assert [int(r[2]) for r in rows[1:]] == list(range(1, len(rows)))
+    assert "Processed 40 sequences, match rate: 15.0%" in (out / "log.txt").read_text()
+
+
 # ------------------------------------------------------------------ synthetic configs
 @pytest.fixture(scope="module")
 def c1(tmp_path_factory):
@@ -249,6 +267,39 @@ def test_length_filter_emits_nothing(lib, c2):
     both = Both(pf, sf, min_length=50)
     got = both.assert_ops_equal(reads, "minlen")
     assert not any(k[0] in ("empty", "one", "short_noprimer") for k in got)
+
+
+# ------------------------------------------------------------------ trace TSV (-d): events == oracle's restatement
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_trace_events_golden(lib, tmp_path, level):
+    """Every event row (worker, sequence number, sequence id, type, fields) of the 40 golden reads, in order.
+    The reference holds no trace fixture (its expected_output/trace files are empty placeholders): parity of the
+    event stream is against the oracle's line-by-line restatement of trace.py / demultiplex.py ("unpinned")."""
+    both = Both(P, S)
+    n = both.assert_trace_equal(golden_reads("sequences.fastq"), level, tmp_path / f"g{level}", "golden")
+    assert n >= {1: 500, 2: 650, 3: 1300}[level]
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(trim="tails"), dict(trim="primers"), dict(trim="none"),
+                                   dict(dereplicate="none"), dict(disable_prefilter=True),
+                                   dict(disable_preorient=True, index_edit_distance=5), dict(min_length=60)],
+                         ids=lambda f: ",".join(f"{k}={v}" for k, v in f.items()) or "default")
+def test_trace_events_flags_and_edge_cases(lib, c2, tmp_path, flags):
+    from specimux_amd import synth
+    pan, (pf, sf) = c2
+    rs = synth.make_reads(pan, 150, 99, windows_only=False)
+    reads = reads_from_set(rs, range(150), 80) + [r for r in _edge_reads(pan) if r[0] != "u_base"]
+    both = Both(pf, sf, **flags)
+    both.assert_trace_equal(reads, 2, tmp_path / "l2", f"edge {flags}")
+    both.assert_trace_equal(reads[:40] + reads[150:190], 3, tmp_path / "l3", f"edge {flags}")
+
+
+def test_trace_multi_pool_panel(lib, c3, tmp_path):
+    from specimux_amd import synth
+    pan, (pf, sf) = c3
+    rs = synth.make_reads(pan, 120, 3003, windows_only=False)
+    both = Both(pf, sf)
+    both.assert_trace_equal(reads_from_set(rs, range(120), 80), 2, tmp_path / "c3", "c3")
 
 
 # ------------------------------------------------------------------ BASELINE-size properties

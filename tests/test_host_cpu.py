@@ -170,3 +170,54 @@ def test_subsample_top_quality(tmp_path):
     got = (tmp_path / "out" / "subsample" / "P" / "F-R" / "s.fastq").read_text()
     assert got == "@a 0,0,0,0 pool=P primers=F+R s\nACGT\n+\nIIII\n@d 0,0,0,0 pool=P primers=F+R s\nACGT\n+\nIIII\n"
     assert (tmp_path / "out" / "subsample" / "P" / "F-R" / "primers.fasta").exists()
+
+
+def test_trace_logger_file_format(tmp_path):
+    """TraceLogger (trace.py:24-107): file name, header, 1-based event counter, verbosity gates, sequence ids."""
+    import csv
+    from specimux_amd.trace import TraceLogger
+
+    class Rec:
+        id = "read/1"
+
+    with TraceLogger(True, 2, str(tmp_path), "worker_7", "20260101_120000", buffer_size=2) as tl:
+        sid = tl.get_sequence_id(Rec(), 41)
+        assert sid == "read/1#00000041#worker_7" and tl.get_sequence_id(Rec()) == "read/1#00000001#worker_7"
+        tl.log_sequence_received(sid, 123, "read/1")
+        tl.log_primer_search(sid, "ITS4", "reverse", 43, 123, False, -1, -1)      # level 2: failed searches are dropped
+        tl.log_primer_search(sid, "ITS4", "reverse", 43, 123, True, 2, 99)
+        tl.log_barcode_search(sid, "ACGT", "reverse", "ITS4", 1, 2, True, 0, 1)   # level 3 only
+        tl.log_orientation_detected(sid, "forward", 2, 0, 1.0)
+        tl.log_sequence_output(sid, "S1", "ITS", "ITS1F-ITS4", "full/ITS/ITS1F-ITS4/S1.fastq")
+    path = tmp_path / "trace" / "specimux_trace_20260101_120000_worker_7.tsv"
+    rows = list(csv.reader(open(path, newline=""), delimiter="\t"))
+    assert rows[0] == ["timestamp", "worker_id", "event_seq", "sequence_id", "event_type"]
+    assert [r[1:] for r in rows[1:]] == [
+        ["worker_7", "1", sid, "SEQUENCE_RECEIVED", "123", "read/1"],
+        ["worker_7", "2", sid, "PRIMER_SEARCH", "ITS4", "reverse", "43", "123", "true", "2", "99"],
+        ["worker_7", "3", sid, "ORIENTATION_DETECTED", "forward", "2", "0", "1.000"],
+        ["worker_7", "4", sid, "SEQUENCE_OUTPUT", "S1", "ITS", "ITS1F-ITS4", "full/ITS/ITS1F-ITS4/S1.fastq"]]
+
+
+def test_oracle_trace_on_golden_reads():
+    """The oracle's trace restatement is self-consistent on the 40 golden reads: one RECEIVED / OUTPUT pair per
+    record, candidate ids dense, level 1 is a subsequence of level 2 is a subsequence of level 3."""
+    from oracle import specimux_oracle as O
+    g = os.path.join(os.path.dirname(__file__), "golden", "integration_test_suite")
+    panel = O.load_panel(f"{g}/primers.fasta", f"{g}/specimens.txt")
+    par = O.setup_params(panel)
+    reads = list(O.read_fastq(f"{g}/sequences.fastq"))
+    streams = {}
+    for level in (1, 2, 3):
+        tr = O.Tracer(level, "main")
+        ops, total, matched = O.process_sequences(reads, par, panel, tr=tr)
+        O.trace_outputs(tr, ops)
+        streams[level] = [tuple(r[2:]) for r in tr.rows]
+        kinds = [r[3] for r in tr.rows]
+        assert (total, matched) == (40, 6)
+        assert kinds.count("SEQUENCE_RECEIVED") == 40 and kinds.count("SEQUENCE_OUTPUT") == len(ops) == 40
+    for lo, hi in ((1, 2), (2, 3)):
+        it = iter(streams[hi])
+        assert all(ev in it for ev in streams[lo]), f"level {lo} is not a subsequence of level {hi}"
+    assert not any(r[1] in ("PRIMER_SEARCH", "BARCODE_SEARCH") for r in streams[1])
+    assert any(r[1] == "BARCODE_SEARCH" for r in streams[3])

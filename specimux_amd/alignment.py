@@ -72,3 +72,29 @@ def align_seq(query, target, max_distance: int, start: int, end: int, mode: str 
     m = AlignmentResult(dist.value, [(starts[i], ends[i]) for i in range(nloc.value)] if dist.value != -1 else [])
     m.adjust_start(s)
     return m
+
+
+def color_sequence(seq: str, quality_scores, p1_location, p2_location, b1_location, b2_location) -> str:
+    """`--color` (alignment.py:59-104): barcodes blue, primers green, bases below Q10 in lower case."""
+    blue, green, reset = "\033[0;34m", "\033[0;32m", "\033[0m"
+    n = len(seq)
+    out = [""] * n
+
+    def paint(location, color):
+        if location is None:
+            return
+        a, e = location
+        if a < 0 or e < 0:
+            return
+        for i in range(a, e + 1):
+            if i < n:
+                out[i] = color + (seq[i].lower() if quality_scores[i] < 10 else seq[i]) + reset
+
+    paint(b1_location, blue)
+    paint(p1_location, green)
+    paint(p2_location, green)
+    paint(b2_location, blue)
+    for i in range(n):
+        if out[i] == "":
+            out[i] = seq[i].lower() if quality_scores[i] < 10 else seq[i]
+    return "".join(out)

@@ -85,13 +85,66 @@ def op_names(panel: CompiledPanel, rec):
     return sample, pool, p1, p2, code, ResolutionType(rtype)
 
 
+class _Locator:
+    """Match locations for `--color` (WriteOperation.p1/p2/b1/b2_location, models.py:262-276): primer locations come
+    from the kernel's hit table, the best barcode's location from the device aligner (the kernel keeps distances, not
+    where each barcode aligned).  Coordinates are those of the candidate's orientation after the trim shift (Q8)."""
+
+    def __init__(self, panel, parameters, prefilter_on):
+        self.panel, self.par, self.prefilter_on = panel, parameters, prefilter_on
+        self.pf_min = (len(panel.barcodes[0]) - parameters.max_dist_index) if prefilter_on else 0
+
+    def _barcode(self, primer, bd_row, sequence, reversed_sequence, L):
+        from .alignment import align_seq
+        from .constants import AlignMode
+        best_d = min((int(d) for d in bd_row[:len(primer.barcodes)] if d >= 0), default=-1)
+        if best_d < 0:
+            return None
+        b = next(b for i, b in enumerate(primer.barcodes) if bd_row[i] == best_d)   # first of the stable sort
+        b_rc = reverse_complement(b)
+        pm = align_seq(primer.primer_rc, sequence, self.par.max_dist_primers[primer.primer], L - self.par.search_len, L)
+        best = None
+        for loc in pm.locations():
+            start = loc[1] + 1
+            if self.prefilter_on:
+                x = sequence[start:][:self.pf_min]
+                if len(x) < self.pf_min or any(ch not in "ACGT" for ch in x):
+                    continue
+            bm = align_seq(b_rc, sequence, self.par.max_dist_index, start, L, AlignMode.PREFIX)
+            if bm.matched() and (best is None or bm.distance() < best.distance()):
+                best = bm
+        if best is None:
+            return None
+        a, e = best.location()
+        return (L - e - 1, L - a - 1) if reversed_sequence else (a, e)
+
+    def locate(self, seq, rseq, rec, hits, bdist, shift):
+        """-> (p1, p2, b1, b2) locations of one record; `shift` = what trim_locations has subtracted so far."""
+        L = len(seq)
+        o = 1 if rec["flags"] & _lib.OPF_REVERSE else 0
+        out = [None, None, None, None]
+        for which, pi in ((1, int(rec["p1"])), (2, int(rec["p2"]))):
+            if pi < 0:
+                continue
+            primer = self.panel.primers[pi]
+            if which == 1:
+                h, sequence, rev = pi * 2 + (0 if o == 0 else 1), (rseq if o == 0 else seq), True
+            else:
+                h, sequence, rev = pi * 2 + (1 if o == 0 else 0), (seq if o == 0 else rseq), False
+            a, e = int(hits[h]["first_start"]), int(hits[h]["first_end"])
+            out[which - 1] = (L - e - 1, L - a - 1) if rev else (a, e)
+            out[which + 1] = self._barcode(primer, bdist[h], sequence, rev, L)
+        return tuple(None if loc is None else (loc[0] - shift, loc[1] - shift) for loc in out)
+
+
 def process_sequences(seq_records, parameters, specimens, args, prefilter, trace_logger=None,
                       record_offset: int = 0) -> Tuple[List[WriteOperation], int, int]:
     """Demultiplex one batch of reads on the GPU; see the module docstring.  With a trace_logger the kernel also
     returns the hit tables it scored from and trace.py replays the reference's events from them."""
     seq_records = list(seq_records)
     tracing = trace_logger is not None and getattr(trace_logger, "enabled", True)
-    panel = compiled_panel(specimens, parameters, args, prefilter, want_starts=tracing)
+    coloring = bool(getattr(args, "color", False)) and not getattr(args, "output_to_files", False)
+    panel = compiled_panel(specimens, parameters, args, prefilter, want_starts=tracing or coloring)
     bases, offsets, seqs = concat_records(seq_records)
     windows, lens = panel.pack_windows(bases, offsets)
     trace_ids = {}
@@ -104,8 +157,12 @@ def process_sequences(seq_records, parameters, specimens, args, prefilter, trace
                                                                           _prefilter_enabled(prefilter))
         trace_ids = _trace.replay_batch(trace_logger, replayer, seq_records, seqs, ops, extra, hits, bdist, op_names,
                                         record_offset)
+    elif coloring:
+        ops, extra, counts, hits, bdist = panel.run(windows, lens, want_hits=True)
     else:
         ops, extra, counts = panel.run(windows, lens)
+    locator = _Locator(panel, parameters, _prefilter_enabled(prefilter)) if coloring else None
+    shifts = {}   # (read, candidate) -> accumulated trim_locations shift (Q8)
     write_ops: List[WriteOperation] = []
     rc_cache = {}
     for i, rec in order_ops(ops, extra):
@@ -123,12 +180,22 @@ def process_sequences(seq_records, parameters, specimens, args, prefilter, trace
         else:
             s, q = seqs[i], qual
         a, b = int(rec["trim_start"]), int(rec["trim_end"])
+        locs = (None, None, None, None)
+        if locator is not None and not (rec["flags"] & _lib.OPF_TRIM_EMPTY) and (rec["p1"] >= 0 or rec["p2"] >= 0):
+            # the record does not name its candidate; (matched primers, orientation, pool) identifies it except when
+            # two candidates of one read share all of those (then their Q8 shifts are pooled: cosmetic, --color only)
+            key = (i, int(rec["p1"]), int(rec["p2"]), int(rec["flags"]) & _lib.OPF_REVERSE, int(rec["pool"]))
+            if getattr(args, "trim", TrimMode.BARCODES) != TrimMode.NONE:
+                shifts[key] = shifts.get(key, 0) + a     # create_write_operation shifts before it reads the locations
+            if i not in rc_cache:
+                rc_cache[i] = (reverse_complement(seqs[i]), qual[::-1])
+            locs = locator.locate(seqs[i], rc_cache[i][0], rec, hits[i], bdist[i], shifts.get(key, 0))
         s, q = s[a:b], q[a:b]
         if rec["flags"] & _lib.OPF_NO_SPECIMEN:
             logging.warning(f"No Specimens for combo: read {record.id} ({code}, {p1}, {p2})")
         write_ops.append(WriteOperation(
             sample_id=sample, seq_id=record.id, distance_code=code, sequence=s, quality_sequence=q,
-            quality_scores=[ord(c) - 33 for c in q], p1_location=None, p2_location=None, b1_location=None,
-            b2_location=None, primer_pool=pool, p1_name=p1, p2_name=p2, resolution_type=rtype,
+            quality_scores=[ord(c) - 33 for c in q], p1_location=locs[0], p2_location=locs[1], b1_location=locs[2],
+            b2_location=locs[3], primer_pool=pool, p1_name=p1, p2_name=p2, resolution_type=rtype,
             trace_sequence_id=trace_ids.get(i)))
     return write_ops, len(seq_records), int(counts[_lib.CNT_MATCHED])

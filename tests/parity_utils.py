@@ -76,6 +76,32 @@ class Both:
                                  f"  oracle: {[k[1:7] + (len(k[7]),) for k in by_e.get(rid, [])]}\n  seq: {seq}")
         return got
 
+    # ------------------------------------------------------------------ match locations (--color)
+    def assert_locations_equal(self, reads, label=""):
+        """p1/p2/b1/b2 locations of every record (what --color paints) against the oracle's CandidateMatch state.
+        Trim-to-empty fallback records are skipped: the kernel's record no longer names their candidate."""
+        from specimux_amd.demultiplex import process_sequences
+        from specimux_amd.io_utils import SeqRecord
+        recs = [SeqRecord(s, rid, rid, q) for rid, s, q in reads]
+        self.args.color, self.args.output_to_files = True, False
+        try:
+            ops, _t, _m = process_sequences(recs, self.parameters, self.specimens, self.args, self.prefilter)
+        finally:
+            self.args.color = False
+        oops, _t, _m = O.process_sequences(reads, self.opar, self.opanel)
+        assert len(ops) == len(oops)
+        n = 0
+        for g, e in zip(ops, oops):
+            assert g.seq_id == e.seq_id and g.sequence == e.sequence
+            if e.sample_id == "unknown" and e.pool == "unknown" and e.p1 == "unknown" and e.p2 == "unknown" and \
+                    (e.p1_loc or e.p2_loc):
+                continue   # fallback record
+            got = (g.p1_location, g.p2_location, g.b1_location, g.b2_location)
+            exp = (e.p1_loc, e.p2_loc, e.b1_loc, e.b2_loc)
+            assert got == exp, f"{label}: read {g.seq_id} ({e.sample_id}, {e.code}): gpu {got} oracle {exp}"
+            n += sum(1 for x in exp if x is not None)
+        return n
+
     # ------------------------------------------------------------------ trace events (-d)
     def product_trace(self, reads, level, out_dir, worker_id="main", record_offset=0):
         """Rows of the TSV the product writes for this batch, without the timestamp column."""

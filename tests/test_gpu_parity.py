@@ -302,6 +302,32 @@ def test_trace_multi_pool_panel(lib, c3, tmp_path):
     both.assert_trace_equal(reads_from_set(rs, range(120), 80), 2, tmp_path / "c3", "c3")
 
 
+@pytest.mark.parametrize("flags", [dict(), dict(trim="primers"), dict(trim="tails"), dict(trim="none")],
+                         ids=lambda f: ",".join(f"{k}={v}" for k, v in f.items()) or "default")
+def test_color_locations(lib, c2, flags):
+    """--color: the primer / barcode locations painted on the (trimmed, oriented) record."""
+    from specimux_amd import synth
+    from specimux_amd.alignment import color_sequence
+    pan, (pf, sf) = c2
+    rs = synth.make_reads(pan, 120, 41, windows_only=False)
+    reads = reads_from_set(rs, range(120), 80) + [r for r in _edge_reads(pan) if r[0] != "u_base"][:60]
+    assert Both(pf, sf, **flags).assert_locations_equal(reads, f"c2 {flags}") > 200
+    assert Both(P, S, **flags).assert_locations_equal(golden_reads("sequences.fastq"), f"golden {flags}") > 40
+    painted = color_sequence("ACGTACGT", [40, 5, 40, 40, 40, 40, 5, 40], (1, 2), None, (0, 0), (6, 9))
+    assert painted == "\033[0;34mA\033[0m\033[0;32mc\033[0m\033[0;32mG\033[0mTAC\033[0;34mg\033[0m\033[0;34mT\033[0m"
+
+
+def test_cli_stdout_color(lib, capsys):
+    """`specimux primers specimens reads -n 8 --color` (stdout mode, orchestration.py:458-545): four lines per
+    record, header "<id> <distance code> <sample>", the matched regions wrapped in ANSI colours."""
+    from specimux_amd import cli
+    cli.main(["specimux", P, S, f"{GOLDEN}/sequences.fastq", "-n", "8", "--color"])
+    out = capsys.readouterr().out.splitlines()
+    assert len(out) == 8 * 4 and all(line.startswith("@") for line in out[0::4])
+    assert out[4].split()[2] == "TEST_SPECIMEN_001"            # second golden read is a full match
+    assert "\033[0;32m" in out[5] and "\033[0;34m" not in out[5]   # trim=barcodes keeps the primers, cuts the barcodes
+
+
 # ------------------------------------------------------------------ BASELINE-size properties
 def test_full_size_properties_765k(lib, c2):
     """configs[1]: 768 specimens, 765k reads.  Size-independent properties + an oracle spot check."""

@@ -177,6 +177,8 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    if world > 1:   # warm-up of the exchange too: the first collective on a fresh communicator sets up its rings
+        reducer.allreduce_(torch.zeros_like(d_counts), stream.cuda_stream)
     torch.cuda.synchronize()
     d_counts.zero_()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]

@@ -1096,8 +1096,12 @@ __global__ __launch_bounds__(NT, BSV == 1 ? 5 : 4) void demux_kernel(DevPanel Pv
         __syncthreads();
         STAMP(1);
 
-        // ---- phase 3a: orientation, which ends need barcodes; scans of locations (A) and searched hits (B)
-        for (int item = tid; item < nh; item += NT) {
+        // ---- phase 3a: orientation, which ends need barcodes; block-wide scans of locations and searched hits;
+        //      one *entry* per optimal primer location of every searched hit
+        if (dbg_bdist)
+            for (int i = tid; i < nh * maxB; i += NT) dbg_bdist[(size_t)r0 * H * maxB + i] = -1;
+        // which ends need barcodes (find_candidate_matches:677-741) -> number of locations to search
+        auto locations_needed = [&](int item) -> int {
             int r = item / H, h = item - r * H, p = h >> 1, X = h & 1;
             int L = lensC[r];
             int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
@@ -1114,32 +1118,111 @@ __global__ __launch_bounds__(NT, BSV == 1 ? 5 : 4) void demux_kernel(DevPanel Pv
                 hl.bbest = -1;
                 n = hl.nloc;
             }
-            offsA[item] = n;
-            offsB[item] = n > 0 ? 1 : 0;
             for (int w = 0; w < MBW; w++) tiem[item * MBW + w] = 0;
+            return n;
+        };
+        // the optimal locations of one searched hit -> entries e, e+1, ... (target start, prefilter verdict)
+        auto list_entries = [&](int item, int rank_in_round, int e) {
+            int r = item / H, h = item - r * H, X = h & 1;
+            const HitL &hl = hits[item];
+            int L = lensC[r];
+            EndGeom g = end_geom(L, S);
+            const unsigned *mrow = masks + (size_t)item * MW;
+            const unsigned *na = namask + (r * 2 + X) * MW;
+            int ord = 0;
+            for (int w = hl.jstar >> 5; w < MW; w++) {
+                unsigned word = mrow[w];
+                if (w == (hl.jstar >> 5)) word &= ~0u << (hl.jstar & 31);
+                while (word) {
+                    int je = w * 32 + __ffs(word) - 1;
+                    word &= word - 1;
+                    int bstart = (je - g.j_lo) + g.shift + 1;
+                    BcGeom bg = bc_geom(L, g.base, bstart);
+                    int ncol = g.Sp - bg.tj0;
+                    bool ok = ncol > 0;
+                    if (ok && pfmin > 0) {   // exact-set restatement of BloomPrefilter.match (Q7)
+                        if (!bg.pf_same || ncol < pfmin) ok = false;
+                        else {   // any non-ACGT code among target[0 : pfmin) ?
+                            int wi = bg.tj0 >> 5, sh = bg.tj0 & 31;
+                            unsigned long long two = ((unsigned long long)(wi + 1 < MW ? na[wi + 1] : 0u) << 32) | na[wi];
+                            if ((two >> sh) & ((1ull << pfmin) - 1ull)) ok = false;
+                        }
+                    }
+                    EntL en;
+                    en.hit = (unsigned short)item;
+                    en.slot = (unsigned short)(rank_in_round << logG);
+                    en.tj0 = (unsigned char)(ok ? bg.tj0 : 0);
+                    en.loc_ord = (unsigned char)ord;
+                    en.ncol = (unsigned char)(ncol > 255 ? 255 : (ncol < 0 ? 0 : ncol));
+                    en.ok = ok ? 1 : 0;
+                    ents[e++] = en;
+                    ord++;
+                }
+            }
+        };
+        bool prelisted = false;   // the usual case: one item per lane and everything fits one round ->
+        int nq = 0, nE_pre = 0;   // scans by shuffles, entries listed by the hit's own lane, three barriers fewer
+        if (nh <= NT) {
+            const int item = tid;
+            const int n = item < nh ? locations_needed(item) : 0;
+            const unsigned pk = (unsigned)n | ((n > 0 ? 1u : 0u) << 16);   // locations | searched hits << 16
+            unsigned incl = pk;
+            for (int d = 1; d < 64; d <<= 1) {
+                unsigned v = (unsigned)__shfl_up((int)incl, d, 64);
+                if ((tid & 63) >= d) incl += v;
+            }
+            unsigned *wsum = (unsigned *)offsB;
+            if ((tid & 63) == 63) wsum[wave] = incl;
+            __syncthreads();
+            unsigned base = 0, total = 0;
+            for (int w = 0; w < NT / 64; w++) { unsigned v = wsum[w]; total += v; base += w < wave ? v : 0u; }
+            const unsigned excl = base + incl - pk;
+            nq = (int)(total >> 16);
+            const int totE = (int)(total & 0xFFFFu);
+            if (nq <= T.CAPH && totE <= T.CAPE) {
+                prelisted = true;
+                nE_pre = totE;
+                if (n > 0) {
+                    queue[excl >> 16] = (unsigned short)item;
+                    list_entries(item, (int)(excl >> 16), (int)(excl & 0xFFFFu));
+                }
+                if (use_slots) { for (int i = tid; i < (nq << logG); i += NT) bres[i] = 0xFFFFFFFFu; }
+                else { for (int i = tid; i < nq * (kidx + 1) * MBW; i += NT) dmask[i] = 0; }
+                __syncthreads();
+            } else {   // several rounds: hand the scans over to the general code below
+                __syncthreads();   // wsum (in offsB) has been read by everyone
+                if (item < nh) {
+                    offsA[item] = (int)(excl & 0xFFFFu);
+                    offsB[item] = (int)(excl >> 16);
+                    if (n > 0) queue[excl >> 16] = (unsigned short)item;
+                }
+                if (tid == 0) { offsA[nh] = totE; offsB[nh] = nq; }
+                __syncthreads();
+            }
+        } else {
+            for (int item = tid; item < nh; item += NT) {
+                int n = locations_needed(item);
+                offsA[item] = n;
+                offsB[item] = n > 0 ? 1 : 0;
+            }
+            __syncthreads();
+            if (wave == 0) wave_exclusive_scan(offsA, nh);
+            else if (wave == 1) wave_exclusive_scan(offsB, nh);
+            __syncthreads();
+            for (int item = tid; item < nh; item += NT)
+                if (offsB[item + 1] != offsB[item]) queue[offsB[item]] = (unsigned short)item;
+            nq = offsB[nh];
+            __syncthreads();
         }
-        if (dbg_bdist)
-            for (int i = tid; i < nh * maxB; i += NT) dbg_bdist[(size_t)r0 * H * maxB + i] = -1;
-        __syncthreads();
-        if (wave == 0) wave_exclusive_scan(offsA, nh);
-        else if (wave == 1) wave_exclusive_scan(offsB, nh);
-        __syncthreads();
-        for (int item = tid; item < nh; item += NT)
-            if (offsB[item + 1] != offsB[item]) queue[offsB[item]] = (unsigned short)item;
-#if defined(SMX_EXP) && SMX_EXP == 6
-        const int nq = 0;
-#else
-        const int nq = offsB[nh];
-#endif
-        __syncthreads();
         STAMP(2);
 
         // ---- phase 3b/3c in rounds of at most CAPH searched hits and CAPE (hit, location) entries
         for (int q0 = 0; q0 < nq;) {
-            int q1;
-            {
+            int q1, nE;
+            if (prelisted) { q1 = nq; nE = nE_pre; }
+            else {
                 int e_base = offsA[queue[q0]];
-                if (nq - q0 <= T.CAPH && offsA[nh] - e_base <= T.CAPE) q1 = nq;   // everything left fits (usual case)
+                if (nq - q0 <= T.CAPH && offsA[nh] - e_base <= T.CAPE) q1 = nq;   // everything left fits
                 else {
                     if (tid == 0) {
                         int q = q0 + 1;   // one hit always fits: CAPE >= 256 >= its locations
@@ -1153,53 +1236,17 @@ __global__ __launch_bounds__(NT, BSV == 1 ? 5 : 4) void demux_kernel(DevPanel Pv
                     __syncthreads();
                     q1 = aggr[8];
                 }
-            }
-            const int e_base = offsA[queue[q0]];
-            const int e_end = (q1 < nq) ? offsA[queue[q1]] : offsA[nh];
-            const int nE = e_end - e_base;
-            // entries: one thread per searched hit of the round lists its optimal locations
-            for (int q = q0 + tid; q < q1; q += NT) {
-                int item = queue[q];
-                int r = item / H, h = item - r * H, X = h & 1;
-                const HitL &hl = hits[item];
-                int L = lensC[r];
-                EndGeom g = end_geom(L, S);
-                const unsigned *mrow = masks + (size_t)item * MW;
-                const unsigned *na = namask + (r * 2 + X) * MW;
-                int e = offsA[item] - e_base, ord = 0;
-                for (int w = hl.jstar >> 5; w < MW; w++) {
-                    unsigned word = mrow[w];
-                    if (w == (hl.jstar >> 5)) word &= ~0u << (hl.jstar & 31);
-                    while (word) {
-                        int je = w * 32 + __ffs(word) - 1;
-                        word &= word - 1;
-                        int bstart = (je - g.j_lo) + g.shift + 1;
-                        BcGeom bg = bc_geom(L, g.base, bstart);
-                        int ncol = g.Sp - bg.tj0;
-                        bool ok = ncol > 0;
-                        if (ok && pfmin > 0) {   // exact-set restatement of BloomPrefilter.match (Q7)
-                            if (!bg.pf_same || ncol < pfmin) ok = false;
-                            else {   // any non-ACGT code among target[0 : pfmin) ?
-                                int wi = bg.tj0 >> 5, sh = bg.tj0 & 31;
-                                unsigned long long two = ((unsigned long long)(wi + 1 < MW ? na[wi + 1] : 0u) << 32) | na[wi];
-                                if ((two >> sh) & ((1ull << pfmin) - 1ull)) ok = false;
-                            }
-                        }
-                        EntL en;
-                        en.hit = (unsigned short)item;
-                        en.slot = (unsigned short)((q - q0) << logG);
-                        en.tj0 = (unsigned char)(ok ? bg.tj0 : 0);
-                        en.loc_ord = (unsigned char)ord;
-                        en.ncol = (unsigned char)(ncol > 255 ? 255 : (ncol < 0 ? 0 : ncol));
-                        en.ok = ok ? 1 : 0;
-                        ents[e++] = en;
-                        ord++;
-                    }
+                const int e_end = (q1 < nq) ? offsA[queue[q1]] : offsA[nh];
+                nE = e_end - e_base;
+                // entries: one thread per searched hit of the round lists its optimal locations
+                for (int q = q0 + tid; q < q1; q += NT) {
+                    int item = queue[q];
+                    list_entries(item, q - q0, offsA[item] - e_base);
                 }
+                if (use_slots) { for (int i = tid; i < ((q1 - q0) << logG); i += NT) bres[i] = 0xFFFFFFFFu; }
+                else { for (int i = tid; i < (q1 - q0) * (kidx + 1) * MBW; i += NT) dmask[i] = 0; }
+                __syncthreads();
             }
-            if (use_slots) { for (int i = tid; i < ((q1 - q0) << logG); i += NT) bres[i] = 0xFFFFFFFFu; }
-            else { for (int i = tid; i < (q1 - q0) * (kidx + 1) * MBW; i += NT) dmask[i] = 0; }
-            __syncthreads();
             STAMP(3);
 
             // 3b (lean, uniform barcode length): bit-sliced scan, one lane per (entry, 32-barcode word).  Two separate

@@ -1262,7 +1262,12 @@ __global__ __launch_bounds__(NT, BSV == 1 ? 5 : 4) void demux_kernel(DevPanel Pv
                     unsigned *dm = dmask + ((en.slot >> logG) * (kidx + 1)) * MBW + w;
                     if constexpr (BSV == 1) {
                         unsigned seen[4];
-                        bitsliced_shw_pad<3, 16>(bsre + (p * MBW + w) * T.BSP, cwt, en.ncol, bsm, kidx, seen);
+                        // padded height: the smallest instantiated M >= barcode length (uniform branch)
+                        const unsigned *reb = bsre + (p * MBW + w) * T.BSP;
+                        if (bsm == 13) bitsliced_shw_pad<3, 13>(reb, cwt, en.ncol, bsm, kidx, seen);
+                        else if (bsm <= 8 && bsm > 3) bitsliced_shw_pad<3, 8>(reb, cwt, en.ncol, bsm, kidx, seen);
+                        else if (bsm <= 12 && bsm > 3) bitsliced_shw_pad<3, 12>(reb, cwt, en.ncol, bsm, kidx, seen);
+                        else bitsliced_shw_pad<3, 16>(reb, cwt, en.ncol, bsm, kidx, seen);
 #pragma unroll
                         for (int d = 0; d < 4; d++)
                             if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);

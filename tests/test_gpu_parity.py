@@ -467,7 +467,8 @@ def _custom_panel(tmp_path_factory, name, n_fwd, n_rev, bc_len, min_dist, fwd_pr
     return pan, tmp_panel(tmp_path_factory, files, name)
 
 
-@pytest.mark.parametrize("shape", ["96x4_multiword", "24nt_barcodes", "40nt_primer_64bit", "mixed_lengths"])
+@pytest.mark.parametrize("shape", ["96x4_multiword", "24nt_barcodes", "40nt_primer_64bit", "mixed_lengths",
+                                   "8nt_barcodes", "10nt_barcodes", "16nt_barcodes"])
 def test_panel_shapes(lib, tmp_path_factory, shape):
     from specimux_amd import synth
     flags = {}
@@ -479,6 +480,9 @@ def test_panel_shapes(lib, tmp_path_factory, shape):
     elif shape == "40nt_primer_64bit":  # primer longer than 32 nt: 64-bit primer words
         pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 8, 6, 13, 6,
                                       fwd_primer="CTTGGTCATTTAGAGGAAGTAAAAGTCGTAACAAGGTTTCC")
+    elif shape.endswith("nt_barcodes"):   # the padded bit-sliced scan's other heights: M = 8, 12, 16 rows
+        n = int(shape.split("nt")[0])
+        pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 8, 6, n, {8: 4, 10: 5, 16: 7}[n])
     else:
         pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 8, 6, 13, 6, mixed=True)
         flags = dict(disable_prefilter=True)

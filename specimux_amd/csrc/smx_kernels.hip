@@ -971,35 +971,40 @@ __global__ __launch_bounds__(NT, BSV == 1 ? 5 : 4) void demux_kernel(DevPanel Pv
 #if defined(SMX_EXP) && SMX_EXP == 7
             g.Sp = 0; g.j_lo = 1;   // timing experiment: no primer columns
 #endif
-            if (sizeof(PW) == 4 && g.j_lo == 0 && (g.Sp & 3) == 0 && g.Sp > 0) {
-                // common case, 32-bit patterns: four columns per group, the next group's Eq words are fetched
-                // before the current group is computed (the compiler otherwise waits on every LDS read), and the
-                // "new minimum" / "equals minimum" flags are shifted into bit-reversed words via the carry flag
-                const int Sp = g.Sp;
+            if (sizeof(PW) == 4 && g.j_lo == 0 && g.Sp == S && (S & 3) == 0) {
+                // common case (full window, 32-bit patterns): four columns per group, the next group's Eq words are
+                // fetched before the current group is computed (the compiler otherwise waits on every LDS read); the
+                // group loop is unrolled by two with ping-pong registers and has uniform (scalar) trip counts; the
+                // "new minimum" / "above minimum" flags are funnel-shifted into bit-reversed words
                 const unsigned *cw4 = (const unsigned *)cw;
                 const unsigned *pq = (const unsigned *)ppeq + p;
                 unsigned Pu = ~0u, Mu = 0;
                 int sc = m, bst = m + 1;
-                unsigned cd = cw4[0];
-                unsigned e0 = pq[(cd & 0xFF) << lNPs], e1 = pq[((cd >> 8) & 0xFF) << lNPs],
-                         e2 = pq[((cd >> 16) & 0xFF) << lNPs], e3 = pq[(cd >> 24) << lNPs];
-                const int last4 = (Sp >> 2) - 1;
-                for (int w = 0; w < MW; w++) {
-                    const int ncols = Sp - w * 32 < 32 ? Sp - w * 32 : 32;
-                    // ltw: "new minimum" flags, gtw: "above the minimum" flags; the newest column is bit 0.  Both
-                    // are sign bits of a difference funnel-shifted in (v_alignbit): no compare, no select.
-                    unsigned gtw = 0, ltw = 0;
-                    for (int gi = 0; gi < (ncols >> 2); gi++) {
-                        int nx = w * 8 + gi + 1;
-                        cd = cw4[nx < last4 ? nx : last4];
-                        unsigned n0 = pq[(cd & 0xFF) << lNPs], n1 = pq[((cd >> 8) & 0xFF) << lNPs],
-                                 n2 = pq[((cd >> 16) & 0xFF) << lNPs], n3 = pq[(cd >> 24) << lNPs];
+                const int ngroups = S >> 2, last4 = ngroups - 1;   // uniform
+#define SMX_PFETCH(G, A0, A1, A2, A3) do { const int g_ = (G) < last4 ? (G) : last4; const unsigned cd_ = cw4[g_];     \
+                         A0 = pq[(cd_ & 0xFF) << lNPs]; A1 = pq[((cd_ >> 8) & 0xFF) << lNPs];                           \
+                         A2 = pq[((cd_ >> 16) & 0xFF) << lNPs]; A3 = pq[(cd_ >> 24) << lNPs]; } while (0)
 #define SMX_PCOL(E) do { myers_step_hw_top(E, Pu, Mu, sc);                                             \
                          ltw = __builtin_amdgcn_alignbit(ltw, (unsigned)(sc - bst), 31);                \
                          gtw = __builtin_amdgcn_alignbit(gtw, (unsigned)(bst - sc), 31);                \
                          bst = sc < bst ? sc : bst; } while (0)
+                unsigned e0, e1, e2, e3, n0, n1, n2, n3;
+                SMX_PFETCH(0, e0, e1, e2, e3);
+                for (int w = 0; w < MW; w++) {
+                    const int gcount = ngroups - w * 8 < 8 ? ngroups - w * 8 : 8;   // groups in this word (uniform)
+                    const int ncols = gcount * 4;
+                    // ltw: "new minimum" flags, gtw: "above the minimum" flags; the newest column is bit 0
+                    unsigned gtw = 0, ltw = 0;
+                    int gi = 0;
+                    for (; gi + 1 < gcount; gi += 2) {
+                        SMX_PFETCH(w * 8 + gi + 1, n0, n1, n2, n3);
                         SMX_PCOL(e0); SMX_PCOL(e1); SMX_PCOL(e2); SMX_PCOL(e3);
-#undef SMX_PCOL
+                        SMX_PFETCH(w * 8 + gi + 2, e0, e1, e2, e3);
+                        SMX_PCOL(n0); SMX_PCOL(n1); SMX_PCOL(n2); SMX_PCOL(n3);
+                    }
+                    if (gi < gcount) {   // odd group count
+                        SMX_PFETCH(w * 8 + gi + 1, n0, n1, n2, n3);
+                        SMX_PCOL(e0); SMX_PCOL(e1); SMX_PCOL(e2); SMX_PCOL(e3);
                         e0 = n0; e1 = n1; e2 = n2; e3 = n3;
                     }
                     // column c of this word sits at bit ncols-1-c
@@ -1008,6 +1013,8 @@ __global__ __launch_bounds__(NT, BSV == 1 ? 5 : 4) void demux_kernel(DevPanel Pv
                         if (ltw) jstar = w * 32 + ncols - __ffs(ltw);
                     } else mrow[w] = 0;
                 }
+#undef SMX_PCOL
+#undef SMX_PFETCH
                 best = bst; score = sc;
                 Pvv = (PW)Pu; Mv = (PW)Mu;
                 for (int w = jstar >> 5; w < MW; w++) {

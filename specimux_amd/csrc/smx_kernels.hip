@@ -851,7 +851,7 @@ __device__ inline void score_general(Emitter &E, int ori) {
 // BSV selects the barcode scan compiled into the kernel (one variant per kernel keeps their register allocations
 // apart): 0 = per-barcode bit-vector scan only, 1 = bit-sliced, k <= 3 (padded 7-row window), 2 = bit-sliced, k 4..7.
 template <typename PW, int NT, int BSV>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
-__global__ __launch_bounds__(NT, BSV == 1 ? 5 : 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
+__global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,

@@ -58,12 +58,24 @@ int io_threads() {
                 }
                 fclose(f);
             }
-            v = std::min(v, 8);
+            v = std::min(v, 16);   // reader, packer and writer overlap: more threads than this only add contention
         }
         return std::max(v, 1);
     }();
     return n;
 }
+
+// uninitialised byte buffer (a std::vector would zero-fill hundreds of MB per batch before they are overwritten)
+struct Blob {
+    char *p = nullptr;
+    size_t n = 0;
+    explicit Blob(size_t len) : p((char *)malloc(len ? len : 1)), n(len) {}
+    ~Blob() { free(p); }
+    Blob(const Blob &) = delete;
+    Blob &operator=(const Blob &) = delete;
+    char *data() { return p; }
+    void resize(size_t m) { n = m; }   // shrink only
+};
 
 struct Rec {
     uint64_t id_off, seq_off, qual_off;   // into the segment's base; qual_off == UINT64_MAX for FASTA
@@ -82,7 +94,7 @@ struct Segment {
 struct smx_batch {
     std::vector<Segment> segs;
     std::vector<uint32_t> first;          // first[i] = global index of segs[i].recs[0]; first.back() = total
-    std::shared_ptr<std::vector<char>> block;   // fast engine: the file block the segments point into
+    std::shared_ptr<Blob> block;   // fast engine: the file block the segments point into
     uint32_t n = 0;
 
     void clear() { segs.clear(); first.clear(); block.reset(); n = 0; }
@@ -304,17 +316,34 @@ int next_fast(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batch *
     for (;;) {
         uint64_t len = std::min<uint64_t>(want, r->fsize - r->fpos);
         bool last_block = r->fpos + len >= r->fsize;
-        auto block = std::make_shared<std::vector<char>>(len);
+        auto block = std::make_shared<Blob>(len);
+        if (!block->data()) { smx_set_error(SMX_ERR_ARG, "out of memory reading %s", r->path.c_str()); return -1; }
+        // the block is read by all I/O threads at once (page-cache copies scale with threads)
+        const int TR = io_threads();
+        std::vector<uint64_t> got_t(TR, 0);
+        std::vector<int> err_t(TR, 0);
+        {
+            std::vector<std::thread> rt;
+            for (int t = 0; t < TR; t++)
+                rt.emplace_back([&, t] {
+                    uint64_t lo = len * (uint64_t)t / (uint64_t)TR, hi = len * (uint64_t)(t + 1) / (uint64_t)TR, g = 0;
+                    while (lo + g < hi) {
+                        ssize_t k = pread(r->fd, block->data() + lo + g, (size_t)std::min<uint64_t>(hi - lo - g, 1u << 30),
+                                          (off_t)(r->fpos + lo + g));
+                        if (k < 0) { if (errno == EINTR) continue; err_t[t] = errno; break; }
+                        if (k == 0) break;
+                        g += (uint64_t)k;
+                    }
+                    got_t[t] = g;
+                });
+            for (auto &x : rt) x.join();
+        }
         uint64_t got = 0;
-        while (got < len) {
-            ssize_t k = pread(r->fd, block->data() + got, (size_t)std::min<uint64_t>(len - got, 1u << 30), (off_t)(r->fpos + got));
-            if (k < 0) {
-                if (errno == EINTR) continue;
-                smx_set_error(SMX_ERR_ARG, "read %s: %s", r->path.c_str(), strerror(errno));
-                return -1;
-            }
-            if (k == 0) break;
-            got += (uint64_t)k;
+        for (int t = 0; t < TR; t++) {
+            if (err_t[t]) { smx_set_error(SMX_ERR_ARG, "read %s: %s", r->path.c_str(), strerror(err_t[t])); return -1; }
+            uint64_t lo = len * (uint64_t)t / (uint64_t)TR, hi = len * (uint64_t)(t + 1) / (uint64_t)TR;
+            got = lo + got_t[t];
+            if (got_t[t] < hi - lo) break;   // short read: the file ends here
         }
         if (got < len) { len = got; last_block = true; block->resize(len); }
         const char *base = block->data(), *end = base + len;
@@ -414,6 +443,8 @@ struct smx_writer {
     struct Shard {   // one per writer thread: owns a disjoint set of output files
         std::vector<File> files;
         std::unordered_map<std::string, size_t> index;
+        std::unordered_map<uint64_t, size_t> by_key;        // packed (class, pool, primers, sample) -> file: no string
+        std::unordered_map<uint64_t, std::string> tails;    // work per record once a file has been seen
         std::string scratch;
         int first_errno = 0;
         int rc = 0;
@@ -463,6 +494,17 @@ inline void owners(const smx_op &op, uint32_t T, uint32_t *primary, uint32_t *po
     *pool_level = mix(mix(0xABCDu, (uint32_t)(uint16_t)op.pool), skey) % T;
 }
 
+// Identity of an output file as one integer: record class, pool, primer pair, sample / partial barcode.
+inline uint64_t file_key(const smx_op &op, bool pool_level) {
+    uint64_t cls = op.rtype == SMX_R_UNKNOWN ? 2u : ((op.rtype == SMX_R_PARTIAL_FWD || op.rtype == SMX_R_PARTIAL_REV) ? 1u : 0u);
+    uint64_t skey = op.sample >= 0 ? (uint64_t)(uint32_t)op.sample
+                                   : (cls == 1 ? (1ull << 29) | ((uint64_t)(op.rtype == SMX_R_PARTIAL_REV) << 16) | (uint16_t)op.barcode
+                                               : (1ull << 30) - 1);
+    if (pool_level) return (3ull << 62) | ((uint64_t)(uint16_t)op.pool << 46) | skey;
+    return (cls << 62) | ((uint64_t)(uint16_t)op.pool << 46) | ((uint64_t)(uint8_t)(op.p1 + 1) << 38) |
+           ((uint64_t)(uint8_t)(op.p2 + 1) << 30) | skey;
+}
+
 int write_one(smx_writer *w, smx_writer::Shard &sh, uint32_t me, uint32_t T, const smx_batch *b, const smx_op &op) {
     if (op.rtype == SMX_R_FILTERED) return SMX_OK;
     uint32_t o1, o2;
@@ -480,58 +522,75 @@ int write_one(smx_writer *w, smx_writer::Shard &sh, uint32_t me, uint32_t T, con
         static const std::string unknown = "unknown";
         return (i >= 0 && (size_t)i < v.size()) ? v[(size_t)i] : unknown;
     };
-    std::string sample;
-    if (op.sample >= 0) sample = name(w->specimens, op.sample);
-    else if (op.rtype == SMX_R_PARTIAL_FWD) sample = "barcode_fwd_" + name(w->barcodes, op.barcode);
-    else if (op.rtype == SMX_R_PARTIAL_REV) sample = "barcode_rev_" + name(w->barcodes, op.barcode);
-    else sample = "unknown";
-    const std::string &pool = name(w->pools, op.pool), &p1 = name(w->primers, op.p1), &p2 = name(w->primers, op.p2);
+    // names, header tail and paths are built once per distinct file; afterwards a record costs two hash lookups
+    const uint64_t k1 = file_key(op, false);
+    auto tit = sh.tails.find(k1);
+    size_t f1 = (size_t)-1, f2 = (size_t)-1;
+    if (tit == sh.tails.end() || (mine1 && sh.by_key.find(k1) == sh.by_key.end()) ||
+        (mine2 && sh.by_key.find(file_key(op, true)) == sh.by_key.end())) {
+        std::string sample;
+        if (op.sample >= 0) sample = name(w->specimens, op.sample);
+        else if (op.rtype == SMX_R_PARTIAL_FWD) sample = "barcode_fwd_" + name(w->barcodes, op.barcode);
+        else if (op.rtype == SMX_R_PARTIAL_REV) sample = "barcode_rev_" + name(w->barcodes, op.barcode);
+        else sample = "unknown";
+        const std::string &pool = name(w->pools, op.pool), &p1 = name(w->primers, op.p1), &p2 = name(w->primers, op.p2);
+        if (tit == sh.tails.end())
+            tit = sh.tails.emplace(k1, " pool=" + pool + " primers=" + p1 + "+" + p2 + " " + sample + "\n").first;
+        const char *top = op.rtype == SMX_R_UNKNOWN ? "unknown" : ((op.rtype == SMX_R_PARTIAL_FWD || op.rtype == SMX_R_PARTIAL_REV) ? "partial" : "full");
+        const std::string ext = w->fastq ? ".fastq" : ".fasta";
+        const std::string fname = w->prefix + safe_name(sample) + ext;
+        if (mine1 && sh.by_key.find(k1) == sh.by_key.end())
+            sh.by_key.emplace(k1, w->file_for(sh, std::string(top) + "/" + pool + "/" + p1 + "-" + p2 + "/" + fname));
+        if (mine2 && sh.by_key.find(file_key(op, true)) == sh.by_key.end())   // pool-level aggregate (io_utils.py:256-268)
+            sh.by_key.emplace(file_key(op, true), w->file_for(sh, "full/" + pool + "/" + fname));
+    }
+    if (mine1) f1 = sh.by_key.find(k1)->second;
+    if (mine2) f2 = sh.by_key.find(file_key(op, true))->second;
+    const std::string &tail = tit->second;
     int64_t L = r.seq_len, s = op.trim_start, e = op.trim_end;
     if (s < 0) s = 0;   // the kernel only emits 0 <= s < e <= L for non-empty reads
     if (e > L) e = L;
     if (e < s) e = s;
-    std::string &rec = sh.scratch;
-    rec.clear();
-    rec.push_back(w->fastq ? '@' : '>');
-    rec.append(base + r.id_off, r.id_len);
-    rec.push_back(' ');
+    const size_t n = (size_t)(e - s);
+    // the record is formatted straight into the first destination's pending buffer
+    std::string &dst = sh.files[mine1 ? f1 : f2].pending;
+    const size_t rec0 = dst.size();
+    dst.reserve(rec0 + r.id_len + tail.size() + 2 * n + 32);
+    dst.push_back(w->fastq ? '@' : '>');
+    dst.append(base + r.id_off, r.id_len);
+    dst.push_back(' ');
     for (int k = 0; k < 4; k++) {
-        if (k) rec.push_back(',');
-        if (op.dist[k] < 0) rec.push_back('X'); else rec += std::to_string((int)op.dist[k]);
+        if (k) dst.push_back(',');
+        int d = op.dist[k];
+        if (d < 0) dst.push_back('X');
+        else { if (d >= 100) dst.push_back((char)('0' + d / 100)); if (d >= 10) dst.push_back((char)('0' + (d / 10) % 10)); dst.push_back((char)('0' + d % 10)); }
     }
-    rec += " pool=" + pool + " primers=" + p1 + "+" + p2 + " " + sample + "\n";
+    dst += tail;
     const char *seq = base + r.seq_off;
     const bool rev = (op.flags & SMX_OPF_REVERSE) != 0;
-    size_t at = rec.size();
-    rec.resize(at + (size_t)(e - s));
-    if (!rev) memcpy(&rec[at], seq + s, (size_t)(e - s));
-    else for (int64_t i = s; i < e; i++) rec[at + (size_t)(i - s)] = (char)w->comp[(unsigned char)seq[L - 1 - i]];
-    rec.push_back('\n');
+    size_t at = dst.size();
+    dst.resize(at + n);
+    if (!rev) memcpy(&dst[at], seq + s, n);
+    else { char *o = &dst[at]; const char *src = seq + (L - 1 - s); for (size_t i = 0; i < n; i++) o[i] = (char)w->comp[(unsigned char)src[-(int64_t)i]]; }
+    dst.push_back('\n');
     if (w->fastq) {
-        rec += "+\n";
-        at = rec.size();
-        rec.resize(at + (size_t)(e - s));
-        if (r.qual_off == UINT64_MAX) memset(&rec[at], 'I', (size_t)(e - s));
+        dst += "+\n";
+        at = dst.size();
+        dst.resize(at + n);
+        if (r.qual_off == UINT64_MAX) memset(&dst[at], 'I', n);
         else {
             const char *q = base + r.qual_off;
-            if (!rev) memcpy(&rec[at], q + s, (size_t)(e - s));
-            else for (int64_t i = s; i < e; i++) rec[at + (size_t)(i - s)] = q[L - 1 - i];
+            if (!rev) memcpy(&dst[at], q + s, n);
+            else { char *o = &dst[at]; const char *src = q + (L - 1 - s); for (size_t i = 0; i < n; i++) o[i] = src[-(int64_t)i]; }
         }
-        rec.push_back('\n');
+        dst.push_back('\n');
     }
-    const char *top = op.rtype == SMX_R_UNKNOWN ? "unknown" : ((op.rtype == SMX_R_PARTIAL_FWD || op.rtype == SMX_R_PARTIAL_REV) ? "partial" : "full");
-    const std::string ext = w->fastq ? ".fastq" : ".fasta";
-    const std::string fname = w->prefix + safe_name(sample) + ext;
-    if (mine1) {
-        size_t f = w->file_for(sh, std::string(top) + "/" + pool + "/" + p1 + "-" + p2 + "/" + fname);
-        sh.files[f].pending += rec;
-        if (sh.files[f].pending.size() > (256u << 10)) smx_writer::flush(sh, sh.files[f]);
+    if (mine1 && mine2) {   // same thread owns both files: copy the finished record
+        std::string &d2 = sh.files[f2].pending;
+        d2.append(dst, rec0, std::string::npos);
     }
-    if (mine2) {   // pool-level aggregate of full matches (io_utils.py:256-268)
-        size_t g = w->file_for(sh, "full/" + pool + "/" + fname);
-        sh.files[g].pending += rec;
-        if (sh.files[g].pending.size() > (256u << 10)) smx_writer::flush(sh, sh.files[g]);
-    }
+    if (mine1 && sh.files[f1].pending.size() > (256u << 10)) smx_writer::flush(sh, sh.files[f1]);
+    if (mine2 && sh.files[f2].pending.size() > (256u << 10)) smx_writer::flush(sh, sh.files[f2]);
     return SMX_OK;
 }
 

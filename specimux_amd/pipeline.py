@@ -4,8 +4,11 @@ Replaces the reference's parent-parses / pool-of-workers structure (orchestratio
 SeqIO.parse, pickled 1000-read batches, per-worker lockf+fsync appends) with three overlapped stages in one
 process: native reader + window packer (thread), GPU batch run (main thread), native writer (thread).
 A batch owns its memory, so stage i+1 of batch k overlaps stage i of batch k+1."""
+import os
 import queue
+import sys
 import threading
+import time
 
 import numpy as np
 
@@ -23,6 +26,8 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
     counts = np.zeros(panel.counts_len, dtype=np.uint64)
     q_in, q_out = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
     errors = []
+    timing = {"read": 0.0, "pack": 0.0, "gpu": 0.0, "write": 0.0} if os.environ.get("SMX_PIPELINE_TIMING") else None
+    t_start = time.perf_counter()
 
     def produce():
         try:
@@ -36,12 +41,17 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                 b.close()
             while left is None or left > 0:
                 want = BATCH_READS if left is None else min(BATCH_READS, left)
+                t0 = time.perf_counter()
                 b = reader.next_batch(want, BATCH_BYTES)
                 if b is None:
                     break
                 if left is not None:
                     left -= len(b)
+                t1 = time.perf_counter()
                 windows, lens = b.pack_windows(panel.search_len, panel.window_stride)
+                if timing:
+                    timing["read"] += t1 - t0
+                    timing["pack"] += time.perf_counter() - t1
                 q_in.put((b, windows, lens))
         except BaseException as e:   # surfaced in the main thread
             errors.append(e)
@@ -55,9 +65,12 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                 if item is None:
                     return
                 b, ops, extra = item
+                t0 = time.perf_counter()
                 if not errors:
                     writer.write(b, ops, extra)
                 b.close()
+                if timing:
+                    timing["write"] += time.perf_counter() - t0
         except BaseException as e:
             errors.append(e)
             while q_out.get() is not None:   # keep draining so the main thread never blocks
@@ -73,7 +86,10 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
             if item is None or errors:
                 break
             b, windows, lens = item
+            t0 = time.perf_counter()
             ops, extra, _ = panel.run(windows, lens, counts=counts)
+            if timing:
+                timing["gpu"] += time.perf_counter() - t0
             q_out.put((b, ops, extra))
             if on_batch:
                 on_batch(int(counts[_lib.CNT_TOTAL]), int(counts[_lib.CNT_MATCHED]))
@@ -93,5 +109,10 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
         except Exception:
             pass
         raise errors[0]
+    t0 = time.perf_counter()
     writer.close()
+    if timing:
+        print("[smx pipeline] wall %.3f s: reader %.3f + pack %.3f (thread 1) | gpu %.3f (main) | writer %.3f + close %.3f "
+              "(thread 2)" % (time.perf_counter() - t_start, timing["read"], timing["pack"], timing["gpu"], timing["write"],
+                              time.perf_counter() - t0), file=sys.stderr)
     return int(counts[_lib.CNT_TOTAL]), int(counts[_lib.CNT_MATCHED]), counts, reader.is_fastq

@@ -232,7 +232,7 @@ def main():
                    "reads_per_gpu_per_step": n, "seed": SEED, "parallelism": f"read-sharded x{world}",
                    "matched_fraction": float(matched)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "smx::demux_kernel<unsigned int>",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "smx::demux_kernel<unsigned int, 256, 1>",
                      "kernel_ms_avg": avg_ms, "kernel_ms_min": float(np.min(kernel_ms)),
                      "algorithmic_bytes_per_read": BYTES_PER_READ,
                      "note": "integer-VALU bound, not HBM bound: see DESIGN.md section 5"},

@@ -1221,6 +1221,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             nq = offsB[nh];
             __syncthreads();
         }
+#if defined(SMX_EXP) && SMX_EXP == 6
+        nq = 0;   // instruction-count experiment: no barcode work at all
+#endif
         STAMP(2);
 
         // ---- phase 3b/3c in rounds of at most CAPH searched hits and CAPE (hit, location) entries

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Manual, longer-running parity fuzz (not collected by pytest): GPU records vs the oracle over many seeds, panel
+shapes, flag sets and search lengths.  Run on a GPU box:  python tests/fuzz_parity.py [--seeds 8] [--reads 1200]"""
+import argparse
+import itertools
+import os
+import sys
+import tempfile
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+from parity_utils import Both  # noqa: E402
+
+
+def reads_of(rs, n, S):
+    from parity_utils import reads_from_set
+    return reads_from_set(rs, range(n), S)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=6)
+    ap.add_argument("--reads", type=int, default=1200)
+    a = ap.parse_args()
+    from specimux_amd import synth
+    flag_sets = [dict(), dict(trim="tails"), dict(trim="primers"), dict(dereplicate="none"), dict(disable_prefilter=True),
+                 dict(disable_preorient=True), dict(search_len=64), dict(search_len=120), dict(index_edit_distance=2),
+                 dict(primer_edit_distance=4), dict(index_edit_distance=4, disable_prefilter=True)]
+    tmp = tempfile.mkdtemp(prefix="smx_fuzz_")
+    panels = {"c2": synth.panel_c2(), "c3": synth.panel_c3(), "c1": synth.panel_c1()}
+    files = {}
+    for name, pan in panels.items():
+        d = os.path.join(tmp, name)
+        os.makedirs(d)
+        files[name] = pan.write(d)
+    t0 = time.time()
+    checked = 0
+    for seed, (fi, flags) in itertools.product(range(a.seeds), enumerate(flag_sets)):
+        name = ("c2", "c3", "c1")[(seed + fi) % 3]
+        pan, (pf, sf) = panels[name], files[name]
+        S = flags.get("search_len", 80)
+        rs = synth.make_reads(pan, a.reads, 9000 + 131 * seed + fi, search_len=S, windows_only=False)
+        reads = reads_of(rs, a.reads, S)
+        both = Both(pf, sf, **flags)
+        both.assert_hits_equal(reads[:100], f"{name} seed {seed} {flags}")
+        both.assert_ops_equal(reads, f"{name} seed {seed} {flags}")
+        checked += len(reads)
+        print(f"ok {name} seed {seed} {flags}  ({checked} reads, {time.time() - t0:.0f} s)", flush=True)
+    print(f"fuzz parity OK: {checked} reads")
+
+
+if __name__ == "__main__":
+    main()

@@ -53,8 +53,10 @@ __device__ __forceinline__ void myers_step_hw_top(unsigned Eq, unsigned &Pv, uns
     unsigned Ph = Mv | ~(Xh | Pv);
     unsigned Mh = Pv & Xh;
     score = score + (int)(Ph >> 31) + ((int)Mh >> 31);
-    Ph <<= 1;
-    Mh <<= 1;
+    // x + x instead of x << 1: measured on gfx950 (tools/ubench/valu_rate.hip, primer_col.hip) v_add_u32 issues
+    // faster than v_lshlrev_b32; the asm keeps LLVM from canonicalising the add back into a shift
+    asm("v_add_u32 %0, %1, %1" : "=v"(Ph) : "v"(Ph));
+    asm("v_add_u32 %0, %1, %1" : "=v"(Mh) : "v"(Mh));
     Pv = Mh | ~(Xv | Ph);
     Mv = Ph & Xv;
 }
@@ -972,41 +974,29 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             g.Sp = 0; g.j_lo = 1;   // timing experiment: no primer columns
 #endif
             if (sizeof(PW) == 4 && g.j_lo == 0 && g.Sp == S && (S & 3) == 0) {
-                // common case (full window, 32-bit patterns): four columns per group, the next group's Eq words are
-                // fetched before the current group is computed (the compiler otherwise waits on every LDS read); the
-                // group loop is unrolled by two with ping-pong registers and has uniform (scalar) trip counts; the
-                // "new minimum" / "above minimum" flags are funnel-shifted into bit-reversed words
-                const unsigned *cw4 = (const unsigned *)cw;
+                // common case (full window, 32-bit patterns): eight columns per unrolled block, one byte read per
+                // column (cheaper than unpacking a dword of codes: tools/ubench/primer_col.hip), uniform trip counts;
+                // the "new minimum" / "above minimum" flags are funnel-shifted into bit-reversed words
                 const unsigned *pq = (const unsigned *)ppeq + p;
                 unsigned Pu = ~0u, Mu = 0;
                 int sc = m, bst = m + 1;
-                const int ngroups = S >> 2, last4 = ngroups - 1;   // uniform
-#define SMX_PFETCH(G, A0, A1, A2, A3) do { const int g_ = (G) < last4 ? (G) : last4; const unsigned cd_ = cw4[g_];     \
-                         A0 = pq[(cd_ & 0xFF) << lNPs]; A1 = pq[((cd_ >> 8) & 0xFF) << lNPs];                           \
-                         A2 = pq[((cd_ >> 16) & 0xFF) << lNPs]; A3 = pq[(cd_ >> 24) << lNPs]; } while (0)
-#define SMX_PCOL(E) do { myers_step_hw_top(E, Pu, Mu, sc);                                             \
-                         ltw = __builtin_amdgcn_alignbit(ltw, (unsigned)(sc - bst), 31);                \
-                         gtw = __builtin_amdgcn_alignbit(gtw, (unsigned)(bst - sc), 31);                \
+                const int esh = lNPs + 2;   // byte offset of Eq[code] = code << esh: one v_lshl_add per column
+#define SMX_PCOL(J) do { const unsigned e_ = *(const unsigned *)((const char *)pq + ((unsigned)cw[J] << esh)); \
+                         myers_step_hw_top(e_, Pu, Mu, sc);                                              \
+                         ltw = __builtin_amdgcn_alignbit(ltw, (unsigned)(sc - bst), 31);                  \
+                         gtw = __builtin_amdgcn_alignbit(gtw, (unsigned)(bst - sc), 31);                  \
                          bst = sc < bst ? sc : bst; } while (0)
-                unsigned e0, e1, e2, e3, n0, n1, n2, n3;
-                SMX_PFETCH(0, e0, e1, e2, e3);
                 for (int w = 0; w < MW; w++) {
-                    const int gcount = ngroups - w * 8 < 8 ? ngroups - w * 8 : 8;   // groups in this word (uniform)
-                    const int ncols = gcount * 4;
+                    const int ncols = S - w * 32 < 32 ? S - w * 32 : 32;   // uniform, a multiple of 4
                     // ltw: "new minimum" flags, gtw: "above the minimum" flags; the newest column is bit 0
                     unsigned gtw = 0, ltw = 0;
-                    int gi = 0;
-                    for (; gi + 1 < gcount; gi += 2) {
-                        SMX_PFETCH(w * 8 + gi + 1, n0, n1, n2, n3);
-                        SMX_PCOL(e0); SMX_PCOL(e1); SMX_PCOL(e2); SMX_PCOL(e3);
-                        SMX_PFETCH(w * 8 + gi + 2, e0, e1, e2, e3);
-                        SMX_PCOL(n0); SMX_PCOL(n1); SMX_PCOL(n2); SMX_PCOL(n3);
+                    int j = w * 32;
+                    const int jend = j + ncols;
+                    for (; j + 8 <= jend; j += 8) {
+                        SMX_PCOL(j); SMX_PCOL(j + 1); SMX_PCOL(j + 2); SMX_PCOL(j + 3);
+                        SMX_PCOL(j + 4); SMX_PCOL(j + 5); SMX_PCOL(j + 6); SMX_PCOL(j + 7);
                     }
-                    if (gi < gcount) {   // odd group count
-                        SMX_PFETCH(w * 8 + gi + 1, n0, n1, n2, n3);
-                        SMX_PCOL(e0); SMX_PCOL(e1); SMX_PCOL(e2); SMX_PCOL(e3);
-                        e0 = n0; e1 = n1; e2 = n2; e3 = n3;
-                    }
+                    if (j < jend) { SMX_PCOL(j); SMX_PCOL(j + 1); SMX_PCOL(j + 2); SMX_PCOL(j + 3); }
                     // column c of this word sits at bit ncols-1-c
                     if (ncols > 0) {
                         mrow[w] = __brev(~gtw) >> (32 - ncols);
@@ -1014,7 +1004,6 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     } else mrow[w] = 0;
                 }
 #undef SMX_PCOL
-#undef SMX_PFETCH
                 best = bst; score = sc;
                 Pvv = (PW)Pu; Mv = (PW)Mu;
                 for (int w = jstar >> 5; w < MW; w++) {

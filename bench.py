@@ -218,7 +218,19 @@ def main():
             tj = json.load(fh)
         if tj.get("reads_per_launch") == n:
             traffic = tj.get("hbm_bytes_per_launch")
-    # integer-ALU roofline (the bound that binds): column-steps per read from the closed form of DESIGN.md
+    # secondary, informational: the integer-VALU issue roofline (the bound that binds).  The wave
+    # instructions per launch come from the committed rocprofv3 PMC summary (SQ_INSTS_VALU) of this same workload.
+    valu = None
+    ppath = os.path.join(REPO, "profiles", "r01_h_pmc_summary.json")
+    if a.config == "c2" and os.path.exists(ppath):
+        with open(ppath) as fh:
+            pj = json.load(fh)
+        insts = pj.get("counters_per_launch", {}).get("SQ_INSTS_VALU")
+        if insts and pj.get("hbm", {}).get("reads_per_launch") == n:
+            peak = 256 * 4 * 2.4e9 / 4.0          # wave64 instructions/s: 1024 SIMDs, one per 4 cycles, 2.4 GHz
+            ach = insts / (avg_ms * 1e-3)
+            valu = {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "wave64 VALU instr/s", "frac": ach / peak,
+                    "instr_per_launch": insts, "source": "profiles/r01_h_pmc_summary.json (SQ_INSTS_VALU)"}
     matched = counts[_lib.CNT_MATCHED] / total_reads
     out = {
         "metric": "reads/sec demultiplexed, 768-specimen ITS panel on 765k ONT-style reads",
@@ -238,6 +250,8 @@ def main():
                      "note": "integer-VALU bound, not HBM bound: see DESIGN.md section 5"},
         "cpu_baseline": cpu,
     }
+    if valu:
+        out["valu_roofline"] = valu
     if cpu:
         out["gpu_over_cpu"] = out["value"] / cpu["value"]
     print(json.dumps(out))

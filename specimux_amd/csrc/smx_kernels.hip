@@ -465,9 +465,6 @@ __device__ inline bool tied_has_global(const ReadCtx &c, int h, int gb) {
 
 // Specimens.specimen_for_exact_match (databases.py:232-245): first specimen in file order.
 __device__ inline int specimen_exact(const DevPanel *P, int gb1, int gb2, int f, int r) {
-#if defined(SMX_EXP) && (SMX_EXP == 1 || SMX_EXP == 4)
-    return (gb1 + gb2) % P->NS;   // timing experiment only: no pointer chase
-#endif
     for (int s = P->pairhead[gb1 * P->NB + gb2]; s >= 0; s = P->spec_next[s])
         if (((P->spec_p1m[s] >> f) & 1) && ((P->spec_p2m[s] >> r) & 1)) return s;
     return -1;
@@ -567,12 +564,8 @@ __device__ inline void emit_op(Emitter &E, const CandView *v, int cand_id, int s
     if (rtype == SMX_R_FULL || rtype == SMX_R_DEREP_FULL) E.matched = true;
     // counters
     int cls = (op.rtype == SMX_R_UNKNOWN) ? 2 : ((op.rtype == SMX_R_PARTIAL_FWD || op.rtype == SMX_R_PARTIAL_REV) ? 1 : 0);
-#if !(defined(SMX_EXP) && (SMX_EXP == 3 || SMX_EXP == 4))
     atomicAdd(&E.aggr[3 + cls], 1);
-#endif
-#if !(defined(SMX_EXP) && (SMX_EXP == 2 || SMX_EXP == 4))
     if (cls == 0 && op.sample >= 0) atomicAdd(&E.counts[SMX_CNT_SPECIMEN0 + op.sample], 1ull);
-#endif
     if (E.n == 0) {
         *E.primary = op;
     } else {
@@ -1434,18 +1427,10 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             unsigned long long t_sc0 = 0;
             if (timing) t_sc0 = clock64();   // diagnostic: the scorer wave's own time inside the shared region
             int r = tid;
-#if defined(SMX_EXP) && SMX_EXP == 5
-            if (r < nr) { smx_op op; op.sample = -1; op.trim_start = 0; op.trim_end = lensC[r]; op.pool = -1; op.p1 = op.p2 = -1; op.barcode = -1;
-                op.dist[0] = op.dist[1] = op.dist[2] = op.dist[3] = -1; op.rtype = SMX_R_UNKNOWN; op.flags = 0; op.n_ops = 1; op.read = r0 + r; opsL[r] = op; }
-            if (false) {
-#else
             if (r < nr) {
-#endif
                 int L = lensC[r];
                 bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
-#if !(defined(SMX_EXP) && (SMX_EXP == 3 || SMX_EXP == 4))
                 atomicAdd(&aggr[0], 1);
-#endif
                 if (filtered) {
                     atomicAdd(&aggr[2], 1);
                     smx_op op;
@@ -1466,9 +1451,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     E.n = 0; E.matched = false; E.overflow = false;
                     if (score_fast(E, ori)) {
                         opsL[r].n_ops = (uint16_t)E.n;
-#if !(defined(SMX_EXP) && (SMX_EXP == 3 || SMX_EXP == 4))
                         if (E.matched) atomicAdd(&aggr[1], 1);
-#endif
                         if (E.n > 1) atomicAdd(&aggr[6], 1);
                         if (E.overflow) atomicAdd(&aggr[7], 1);
                     } else if (!SMX_DEFER) {

@@ -384,9 +384,8 @@ __device__ __forceinline__ void bitsliced_shw_pad(const unsigned *re, const unsi
             const unsigned live = c < nlive ? ~0u : 0u;
             const unsigned hi = ~(s4 | s3) & live;
 #pragma unroll
-            for (int d = 0; d <= KB; d++)
-                if (d <= kidx)
-                    seen[d] |= hi & ((d & 1) ? s0 : ~s0) & ((d & 2) ? s1 : ~s1) & ((d & 4) ? s2 : ~s2);
+            for (int d = 0; d <= KB; d++)   // levels above k are computed too (no per-level select); the caller ignores them
+                seen[d] |= hi & ((d & 1) ? s0 : ~s0) & ((d & 2) ? s1 : ~s1) & ((d & 4) ? s2 : ~s2);
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the live ranges column-sized (otherwise ~130 LDS reads get hoisted and spill)
     }

@@ -923,6 +923,12 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 
     const int stride = P->wstride;
     const int kidx = P->kidx, pfmin = P->pfmin;
+    // Integer division by the (uniform, runtime) item strides: a generic `x / H` is a ~30-instruction sequence on the
+    // VALU and sits in every per-item loop.  H is a power of two for 1, 2, 4, 8 ... primers (shift); otherwise one
+    // v_mul_hi with ceil(2^32 / H), exact for x < 2^32 / H (items are < 2^16).
+    const int lH = (H & (H - 1)) == 0 ? 31 - __clz(H) : -1;
+    const unsigned Hmagic = (unsigned)((0x100000000ull + (unsigned)H - 1) / (unsigned)H);
+    auto divH = [&](int x) -> int { return lH >= 0 ? (x >> lH) : (int)__umulhi((unsigned)x, Hmagic); };
     const uint32_t n_tiles = (n_reads + R - 1) / R;
     // diagnostic phase timing (SMX_PHASE_TIMING=1): thread 0 accumulates s_memtime deltas per phase, in LDS so that
     // the accumulators cost no registers in the production path
@@ -953,7 +959,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         if (have) {
         // ---- phase 2: primer scan, one lane per (read, primer, end)
         for (int item = tid; item < nh; item += NT) {
-            int r = item / H, h = item - r * H, p = h >> 1, X = h & 1;
+            int r = divH(item), h = item - r * H, p = h >> 1, X = h & 1;
             int L = lensC[r];
             EndGeom g = end_geom(L, S);
             const unsigned char *cw = codes + (r * 2 + X) * CS;
@@ -1090,7 +1096,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             for (int i = tid; i < nh * maxB; i += NT) dbg_bdist[(size_t)r0 * H * maxB + i] = -1;
         // which ends need barcodes (find_candidate_matches:677-741) -> number of locations to search
         auto locations_needed = [&](int item) -> int {
-            int r = item / H, h = item - r * H, p = h >> 1, X = h & 1;
+            int r = divH(item), h = item - r * H, p = h >> 1, X = h & 1;
             int L = lensC[r];
             int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
             int ori = 3;   // bit0: as-read candidates allowed, bit1: reverse-complement candidates allowed
@@ -1111,7 +1117,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         };
         // the optimal locations of one searched hit -> entries e, e+1, ... (target start, prefilter verdict)
         auto list_entries = [&](int item, int rank_in_round, int e) {
-            int r = item / H, h = item - r * H, X = h & 1;
+            int r = divH(item), h = item - r * H, X = h & 1;
             const HitL &hl = hits[item];
             int L = lensC[r];
             EndGeom g = end_geom(L, S);
@@ -1245,10 +1251,11 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             if (BSV != 0 && use_bs) {
                 const int bsm = P->bs_m;
                 for (int item = tid; item < nE * MBW; item += NT) {
-                    const int ei = item / MBW, w = item - ei * MBW;
+                    int ei = item, w = 0;
+                    if (MBW != 1) { ei = item / MBW; w = item - ei * MBW; }   // MBW == 1 (<= 32 barcodes per primer) is the usual case
                     const EntL en = ents[ei];
                     if (!en.ok) continue;
-                    const int hh = en.hit, h = hh % H, p = h >> 1, X = h & 1, r = hh / H;
+                    const int hh = en.hit, r = divH(hh), h = hh - r * H, p = h >> 1, X = h & 1;
                     const unsigned char *cwt = codes + (r * 2 + X) * CS + en.tj0;
                     unsigned *dm = dmask + ((en.slot >> logG) * (kidx + 1)) * MBW + w;
                     if constexpr (BSV == 1) {
@@ -1275,7 +1282,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             for (int item = tid; item < (nE << logG); item += NT) {
                 const EntL en = ents[item >> logG];
                 int bi = item & (G - 1);
-                int hh = en.hit, h = hh % H, p = h >> 1, X = h & 1, r = hh / H;
+                int hh = en.hit, r = divH(hh), h = hh - r * H, p = h >> 1, X = h & 1;
                 int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
                 if (bi >= nb || !en.ok) continue;
                 int gb = LP.pbc[LP.pbc_off[p] + bi];
@@ -1333,7 +1340,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     const bool in = i < nslots;
                     const int q = q0 + ((in ? i : 0) >> logG), sl = i & (G - 1);
                     const int item = queue[q];
-                    const int r = item / H, h = item - r * H, p = h >> 1;
+                    const int r = divH(item), h = item - r * H, p = h >> 1;
                     const int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
                     const bool live = in && sl < nb;
                     unsigned v = live ? bres[i] : 0xFFFFFFFFu;
@@ -1375,7 +1382,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             for (int q = q0 + tid; q < q1; q += NT) {
                 int item = queue[q];
                 HitL &hl = hits[item];
-                int r = item / H, h = item - r * H, p = h >> 1;
+                int r = divH(item), h = item - r * H, p = h >> 1;
                 int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
                 const unsigned *br = bres + ((q - q0) << logG);
                 unsigned best = 255;
@@ -1518,10 +1525,11 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 // [all tail chunks] so that a wave is (almost always) uniform in role.  Full windows (len >= S):
                 // four LUT lookups -> one packed dword store; the head is written reversed (reverse complement).
                 const int hc = S >> 4, nhead = nrn * hc, S4 = S >> 2;
+                const unsigned hcmagic = (unsigned)((0x100000000ull + (unsigned)hc - 1) / (unsigned)hc);   // k / hc, k < 2^16
                 for (int ci = wid; ci < 2 * nhead; ci += nw) {
                     const bool tail = ci >= nhead;
                     const int k = tail ? ci - nhead : ci;
-                    const int r = k / hc, c = k - r * hc;
+                    const int r = (int)__umulhi((unsigned)k, hcmagic), c = k - r * hc;
                     const uint4 v = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (tail ? S : 0) + 16 * c);
                     const int L = lens[r0n + r];
                     // ACGT fast path, four bases per dword without the LUT: (ch >> 1) & 3 maps A,C,T,G -> 0,1,2,3; swapping 2 and 3
@@ -1566,7 +1574,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         // ---- optional parity dump
         if (have && dbg_hits) {
             for (int item = tid; item < nh; item += NT) {
-                int r = item / H;
+                int r = divH(item);
                 const HitL &hl = hits[item];
                 EndGeom g = end_geom(lensC[r], S);
                 smx_hit o;

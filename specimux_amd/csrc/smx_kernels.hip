@@ -929,6 +929,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     const int lH = (H & (H - 1)) == 0 ? 31 - __clz(H) : -1;
     const unsigned Hmagic = (unsigned)((0x100000000ull + (unsigned)H - 1) / (unsigned)H);
     auto divH = [&](int x) -> int { return lH >= 0 ? (x >> lH) : (int)__umulhi((unsigned)x, Hmagic); };
+    const unsigned hcmagic = (unsigned)((0x100000000ull + (unsigned)(S >> 4) - 1) / (unsigned)((S >> 4) > 0 ? (S >> 4) : 1));   // chunk / (S/16)
     const uint32_t n_tiles = (n_reads + R - 1) / R;
     // diagnostic phase timing (SMX_PHASE_TIMING=1): thread 0 accumulates s_memtime deltas per phase, in LDS so that
     // the accumulators cost no registers in the production path
@@ -1525,7 +1526,6 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 // [all tail chunks] so that a wave is (almost always) uniform in role.  Full windows (len >= S):
                 // four LUT lookups -> one packed dword store; the head is written reversed (reverse complement).
                 const int hc = S >> 4, nhead = nrn * hc, S4 = S >> 2;
-                const unsigned hcmagic = (unsigned)((0x100000000ull + (unsigned)hc - 1) / (unsigned)hc);   // k / hc, k < 2^16
                 for (int ci = wid; ci < 2 * nhead; ci += nw) {
                     const bool tail = ci >= nhead;
                     const int k = tail ? ci - nhead : ci;

@@ -3,16 +3,19 @@
 // One fused kernel per read batch ("demux kernel"), no intermediate HBM traffic: workgroups of 256 threads pull
 // tiles of R reads from a global tile queue; everything between the windows and the 32-byte result records lives
 // in LDS (layout: make_layout).
-//     phase 0  panel tables staged once per workgroup: primer Peq [code][primer], bit-sliced barcode tables
-//              [primer][row][code], ASCII->code LUTs, pair / barcode lists
+// The tile loop is software-pipelined: phase 4 of tile t (one wave) runs beside phase 1 of tile t+1 (three waves).
+//     phase 0  panel tables staged once per workgroup: primer Peq [code][primer] (patterns left-aligned), bit-sliced
+//              barcode tables [primer][32-barcode word][row][code], ASCII->code LUTs, pair / barcode lists
 //     phase 1  coalesced 16-byte loads of the two `search_len` end windows, ASCII -> 4-bit IUPAC code,
 //              window A reverse-complemented on the fly           (demultiplex.py:142, :757-766)
 //     phase 2  primer scan: one lane per (read, primer, end): Myers/Hyyro bit-vector HW (infix) DP,
 //              all optimal end columns kept as an LDS bitmask     (match_one_end :755-770, align_seq)
 //              + orientation votes from the same alignments       (determine_orientation :602-638, A.6)
 //     phase 3  barcode scan per optimal primer location ("entry"), exact-set prefilter rule per entry
-//              lean mode : bit-sliced banded SHW DP, one lane aligns the primer's whole barcode list; results are
-//                          OR-ed into per-hit "barcodes seen at distance d" bitmasks
+//              lean mode : bit-sliced banded SHW DP, one lane aligns the primer's whole barcode list (32 per word)
+//                          in a 7-row register window, barcodes padded to a fixed height by wildcard rows so the
+//                          scan is straight-line code; results are OR-ed into per-hit "barcodes seen at distance
+//                          d" bitmasks
 //              slots mode: one lane per (entry, barcode), bit-vector SHW, LDS atomicMin keeps the best location
 //                          per barcode (needed for --trim tails and the parity dumps)
 //                                                                  (match_one_end :778-815, bloom_filter.py:176)
@@ -20,7 +23,10 @@
 //              resolve_specimen, trim extents -> smx_op records + counters
 //                                                                  (demultiplex.py:108-598, models.py:278-328)
 //
-// Pure integer work: no MFMA.  See DESIGN.md for the data layout, the exactness arguments and the rooflines.
+// Pure integer work: no MFMA.  The kernel is bound by VALU issue; instruction selection follows the measured opcode
+// rates of tools/ubench (bit-ops / add / sub / v_bitop3 are fast; shifts, min, compares, SDWA and three-source VOP3
+// forms are about half rate; generic integer division is avoided in per-item code).  See DESIGN.md for the data
+// layout, the exactness arguments and the rooflines.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "smx.h"

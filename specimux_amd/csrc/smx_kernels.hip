@@ -966,15 +966,15 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         if (have) {
         // ---- phase 2: primer scan, one lane per (read, primer, end)
         for (int item = tid; item < nh; item += NT) {
-            int r = divH(item), h = item - r * H, p = h >> 1, X = h & 1;
+            int r = divH(item), h = item - __mul24(r, H), p = h >> 1, X = h & 1;
             int L = lensC[r];
             EndGeom g = end_geom(L, S);
-            const unsigned char *cw = codes + (r * 2 + X) * CS;
+            const unsigned char *cw = codes + __mul24(r * 2 + X, CS);
             const PW *peq = ppeq + p;
             const int m = LP.pm[p], k = LP.pk[p], top = PWBITS - 1;
             PW Pvv = ~(PW)0, Mv = 0;
             int score = m, best = m + 1, jstar = 0, cnt = 0;
-            unsigned *mrow = masks + (size_t)item * MW;
+            unsigned *mrow = masks + __mul24(item, MW);
 #if defined(SMX_EXP) && SMX_EXP == 7
             g.Sp = 0; g.j_lo = 1;   // timing experiment: no primer columns
 #endif
@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             for (int i = tid; i < nh * maxB; i += NT) dbg_bdist[(size_t)r0 * H * maxB + i] = -1;
         // which ends need barcodes (find_candidate_matches:677-741) -> number of locations to search
         auto locations_needed = [&](int item) -> int {
-            int r = divH(item), h = item - r * H, p = h >> 1, X = h & 1;
+            int r = divH(item), h = item - __mul24(r, H), p = h >> 1, X = h & 1;
             int L = lensC[r];
             int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
             int ori = 3;   // bit0: as-read candidates allowed, bit1: reverse-complement candidates allowed
@@ -1119,17 +1119,17 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 hl.bbest = -1;
                 n = hl.nloc;
             }
-            for (int w = 0; w < MBW; w++) tiem[item * MBW + w] = 0;
+            for (int w = 0; w < MBW; w++) tiem[__mul24(item, MBW) + w] = 0;
             return n;
         };
         // the optimal locations of one searched hit -> entries e, e+1, ... (target start, prefilter verdict)
         auto list_entries = [&](int item, int rank_in_round, int e) {
-            int r = divH(item), h = item - r * H, X = h & 1;
+            int r = divH(item), h = item - __mul24(r, H), X = h & 1;
             const HitL &hl = hits[item];
             int L = lensC[r];
             EndGeom g = end_geom(L, S);
-            const unsigned *mrow = masks + (size_t)item * MW;
-            const unsigned *na = namask + (r * 2 + X) * MW;
+            const unsigned *mrow = masks + __mul24(item, MW);
+            const unsigned *na = namask + __mul24(r * 2 + X, MW);
             int ord = 0;
             for (int w = hl.jstar >> 5; w < MW; w++) {
                 unsigned word = mrow[w];
@@ -1262,13 +1262,13 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     if (MBW != 1) { ei = item / MBW; w = item - ei * MBW; }   // MBW == 1 (<= 32 barcodes per primer) is the usual case
                     const EntL en = ents[ei];
                     if (!en.ok) continue;
-                    const int hh = en.hit, r = divH(hh), h = hh - r * H, p = h >> 1, X = h & 1;
-                    const unsigned char *cwt = codes + (r * 2 + X) * CS + en.tj0;
-                    unsigned *dm = dmask + ((en.slot >> logG) * (kidx + 1)) * MBW + w;
+                    const int hh = en.hit, r = divH(hh), h = hh - __mul24(r, H), p = h >> 1, X = h & 1;
+                    const unsigned char *cwt = codes + __mul24(r * 2 + X, CS) + en.tj0;
+                    unsigned *dm = dmask + __mul24(__mul24(en.slot >> logG, kidx + 1), MBW) + w;
                     if constexpr (BSV == 1) {
                         unsigned seen[4];
                         // padded height: the smallest instantiated M >= barcode length (uniform branch)
-                        const unsigned *reb = bsre + (p * MBW + w) * T.BSP;
+                        const unsigned *reb = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
                         if (bsm == 13) bitsliced_shw_pad<3, 13>(reb, cwt, en.ncol, bsm, kidx, seen);
                         else if (bsm <= 8 && bsm > 3) bitsliced_shw_pad<3, 8>(reb, cwt, en.ncol, bsm, kidx, seen);
                         else if (bsm <= 12 && bsm > 3) bitsliced_shw_pad<3, 12>(reb, cwt, en.ncol, bsm, kidx, seen);
@@ -1289,7 +1289,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             for (int item = tid; item < (nE << logG); item += NT) {
                 const EntL en = ents[item >> logG];
                 int bi = item & (G - 1);
-                int hh = en.hit, r = divH(hh), h = hh - r * H, p = h >> 1, X = h & 1;
+                int hh = en.hit, r = divH(hh), h = hh - __mul24(r, H), p = h >> 1, X = h & 1;
                 int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
                 if (bi >= nb || !en.ok) continue;
                 int gb = LP.pbc[LP.pbc_off[p] + bi];
@@ -1347,7 +1347,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     const bool in = i < nslots;
                     const int q = q0 + ((in ? i : 0) >> logG), sl = i & (G - 1);
                     const int item = queue[q];
-                    const int r = divH(item), h = item - r * H, p = h >> 1;
+                    const int r = divH(item), h = item - __mul24(r, H), p = h >> 1;
                     const int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
                     const bool live = in && sl < nb;
                     unsigned v = live ? bres[i] : 0xFFFFFFFFu;
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             for (int q = q0 + tid; q < q1; q += NT) {
                 int item = queue[q];
                 HitL &hl = hits[item];
-                int r = divH(item), h = item - r * H, p = h >> 1;
+                int r = divH(item), h = item - __mul24(r, H), p = h >> 1;
                 int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
                 const unsigned *br = bres + ((q - q0) << logG);
                 unsigned best = 255;
@@ -1535,7 +1535,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 for (int ci = wid; ci < 2 * nhead; ci += nw) {
                     const bool tail = ci >= nhead;
                     const int k = tail ? ci - nhead : ci;
-                    const int r = (int)__umulhi((unsigned)k, hcmagic), c = k - r * hc;
+                    const int r = (int)__umulhi((unsigned)k, hcmagic), c = k - __mul24(r, hc);
                     const uint4 v = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (tail ? S : 0) + 16 * c);
                     const int L = lens[r0n + r];
                     // ACGT fast path, four bases per dword without the LUT: (ch >> 1) & 3 maps A,C,T,G -> 0,1,2,3; swapping 2 and 3
@@ -1552,7 +1552,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                         pk[q] = tail ? y : __builtin_amdgcn_perm(0u, y ^ 0x03030303u, 0x00010203u);
                     }
                     if (acgt) {
-                        unsigned *dst = (unsigned *)(codes + (r * 2 + (tail ? 1 : 0)) * CS);
+                        unsigned *dst = (unsigned *)(codes + __mul24(r * 2 + (tail ? 1 : 0), CS));
 #pragma unroll
                         for (int q = 0; q < 4; q++) dst[tail ? 4 * c + q : S4 - 1 - (4 * c + q)] = pk[q];
                     } else {

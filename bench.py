@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=N_READS, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3"], help=argparse.SUPPRESS)   # c3: 3072 specimens / 4 pools
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"], help=argparse.SUPPRESS)   # c3: 3072 specimens / 4 pools; c5: + 160-nt windows, 15 % errors
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -116,7 +116,8 @@ def main():
     tmp = tempfile.mkdtemp(prefix="smx_bench_")
     pf, sf = pan.write(tmp)
     from specimux_amd.distributed import shard_seed
-    rs = synth.make_reads(pan, a.reads, shard_seed(SEED, rank))     # this rank's shard (weak scaling)
+    gen_kw = dict(search_len=160, error_rate=0.15) if a.config == "c5" else {}
+    rs = synth.make_reads(pan, a.reads, shard_seed(SEED, rank), **gen_kw)     # this rank's shard (weak scaling)
 
     cpu = None
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
@@ -141,7 +142,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     lib = _lib.load()
-    args = parse_args(["specimux", pf, sf, "reads.fastq"])   # the reference's default flags
+    args = parse_args(["specimux", pf, sf, "reads.fastq"] + (["-l", "160"] if a.config == "c5" else []))   # default flags
     reg = sa.read_primers_file(pf)
     specimens = sa.read_specimen_file(sf, reg)
     specimens.validate()
@@ -210,7 +211,8 @@ def main():
         return
 
     avg_ms = float(np.mean(kernel_ms))
-    achieved = BYTES_PER_READ * n / (avg_ms * 1e-3) / 1e9
+    bytes_per_read = (2 * 160 + 4 + 32) if a.config == "c5" else BYTES_PER_READ
+    achieved = bytes_per_read * n / (avg_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
     if os.path.exists(tpath):
@@ -240,13 +242,14 @@ def main():
         "config": {"workload": ("configs[1]: 768-specimen ONT037-style ITS panel (32x24 13-nt barcodes, ITS1F/ITS4, "
                                 "k_idx=3, k_p=7/6), 765k reads per GPU per step, search_len 80, prefilter+preorient on, "
                                 "trim=barcodes, dereplicate=best") if a.config == "c2" else
-                               "configs[2]-style: 3072 specimens over 4 pools (ITS/RPB2/LSU/TEF1, ITS4 shared), default flags",
+                               ("configs[2]-style: 3072 specimens over 4 pools (ITS/RPB2/LSU/TEF1, ITS4 shared), default flags"
+                                if a.config == "c3" else "configs[4]-style: the 3072-specimen panel, 15 % error reads, -l 160"),
                    "reads_per_gpu_per_step": n, "seed": SEED, "parallelism": f"read-sharded x{world}",
                    "matched_fraction": float(matched)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "smx::demux_kernel<unsigned int, 256, 1>",
                      "kernel_ms_avg": avg_ms, "kernel_ms_min": float(np.min(kernel_ms)),
-                     "algorithmic_bytes_per_read": BYTES_PER_READ,
+                     "algorithmic_bytes_per_read": bytes_per_read,
                      "note": "integer-VALU bound, not HBM bound: see DESIGN.md section 5"},
         "cpu_baseline": cpu,
     }

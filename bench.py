@@ -166,7 +166,6 @@ def main():
     reducer = CountsReducer(world, rank, "torch" if rehearsal else "rccl")
 
     def step():
-        d_nextra.zero_()
         _lib.check(lib.smx_batch_run_device(cp.handle, C.c_void_p(stream.cuda_stream), C.c_void_p(d_windows.data_ptr()),
                                             C.c_void_p(d_lens.data_ptr()), n, C.c_void_p(d_ops.data_ptr()),
                                             C.c_void_p(d_extra.data_ptr()), extra_cap, C.c_void_p(d_nextra.data_ptr()),

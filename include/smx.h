@@ -172,7 +172,8 @@ int smx_pack_windows(const uint8_t *bases, const uint64_t *offsets, uint32_t n_r
  * Run the hot path on windows already resident in device memory.  All pointers are DEVICE pointers;
  * `stream` is a hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing.
  *   d_ops          n_reads records
- *   d_extra        extra_cap records; d_n_extra one uint32 (must be zeroed by the caller)
+ *   d_extra        extra_cap records; d_n_extra one uint32, WRITTEN by the call (number of extra records produced,
+ *                  may exceed extra_cap: then only the first extra_cap were stored); no need to clear it
  *   d_counts       smx_counts_len() uint64, accumulated into (not cleared)
  *   d_hits/d_bdist optional parity dumps (NULL to skip): n_reads*smx_hits_per_read() smx_hit and
  *                  n_reads*smx_bdist_per_read() int8 best distance per (read, primer, end, barcode slot), -1 none

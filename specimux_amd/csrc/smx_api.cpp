@@ -127,7 +127,7 @@ struct smx_panel {
     std::mutex ws_mutex;                     // smx_batch_run is serialised per panel (one workspace)
     DevBuf ws[8];                            // windows, lens, ops, extra, n_extra, counts, hits, bdist
     DevBuf defer;                            // hit-table dumps of the reads deferred to the general scorer
-    unsigned *d_tile_counter = nullptr;      // [0] dynamic tile queue head, [1] deferred-read counter (zeroed on the stream before each launch)
+    unsigned *d_tile_counter = nullptr;      // {tile queue head, deferred reads, finished workgroups, extra records}: self re-arming
     unsigned long long *d_phase = nullptr;   // SMX_PHASE_TIMING diagnostic
     int phase_grid = 0;
 };
@@ -386,6 +386,7 @@ static int ensure_device(smx_panel *P) {
     HIP_TRY(hipMalloc(&P->d_blob, P->blob.size()));
     HIP_TRY(hipMemcpy(P->d_blob, P->blob.data(), P->blob.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void **)&P->d_tile_counter, 64));
+    HIP_TRY(hipMemset(P->d_tile_counter, 0, 64));   // the kernel re-arms these counters itself after every launch
     unsigned char *b = (unsigned char *)P->d_blob;
     smx::DevPanel &h = P->hp;
     h.ppeq = (const unsigned long long *)(b + P->o_ppeq);
@@ -441,7 +442,11 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     if (((uintptr_t)d_windows & 15) != 0) return fail(SMX_ERR_ARG, "window buffer must be 16-byte aligned");
     int rc = ensure_device(P);
     if (rc) return rc;
-    if (n_reads == 0) return SMX_OK;
+    if (n_reads == 0) {   // nothing to launch: the count the kernel would have written
+        if (hipMemsetAsync(d_n_extra, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
+            return fail(SMX_ERR_DEVICE, "cannot clear the extra-record counter");
+        return SMX_OK;
+    }
     // slots mode keeps one result slot per (hit, barcode): needed for the tails extent and for the parity dumps
     const int use_slots = (P->hp.trim == SMX_TRIM_TAILS || d_hits || d_bdist || getenv("SMX_FORCE_SLOTS")) ? 1 : 0;
     const int R = use_slots ? P->R_slots : P->R;

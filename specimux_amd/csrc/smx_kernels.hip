@@ -1459,7 +1459,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     int ori = 3;
                     if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
                     Emitter E;
-                    E.c = &c; E.primary = opsL + r; E.extra = extra; E.extra_cap = extra_cap; E.n_extra = n_extra;
+                    E.c = &c; E.primary = opsL + r; E.extra = extra; E.extra_cap = extra_cap;
+                    E.n_extra = SMX_DEFER ? n_extra : tile_counter + 3;   // see the kernel's epilogue
                     E.counts = counts; E.emitlog = emitlog + r * SMX_MAX_EMIT; E.aggr = aggr; E.read = r0 + r;
                     E.n = 0; E.matched = false; E.overflow = false;
                     if (score_fast(E, ori)) {
@@ -1609,6 +1610,21 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 #undef STAMP
     // block aggregates -> global counters
     if (tid < 8 && aggr[tid]) atomicAdd(&counts[tid], (unsigned long long)aggr[tid]);
+    // The launch counters re-arm themselves: tile_counter = {tile queue head, deferred reads, finished workgroups,
+    // extra records}.  The last workgroup to get here publishes the extra-record count and zeroes the block, so a launch
+    // needs no memset in front of it (two small fills per batch were ~2 % of a 0.4 ms launch).
+    if (!SMX_DEFER) {
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            const unsigned prev = atomicAdd(tile_counter + 2, 1u);
+            if (prev == gridDim.x - 1) {
+                __threadfence();
+                *n_extra = atomicAdd(tile_counter + 3, 0u);
+                tile_counter[0] = 0; tile_counter[2] = 0; tile_counter[3] = 0;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1691,8 +1707,10 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
                                 smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter, int use_slots,
                                 unsigned char *d_defer) {
     hipStream_t s = (hipStream_t)stream;
-    // d_tile_counter[0] = tile queue head, [1] = number of deferred reads
-    hipError_t me = hipMemsetAsync(d_tile_counter, 0, 2 * sizeof(unsigned), s);
+    // d_tile_counter = {tile queue head, deferred reads, finished workgroups, extra records}: zero at allocation, re-armed by
+    // the last workgroup of every launch (the two-kernel build still clears it here)
+    hipError_t me = hipSuccess;
+    if (SMX_DEFER) me = hipMemsetAsync(d_tile_counter, 0, 4 * sizeof(unsigned), s);
     if (me != hipSuccess) return (int)me;
     // one instantiation per (primer word width, barcode scan variant); slots mode never uses the bit-sliced scan
     const int bsv = (use_slots || !P->bs_ok) ? 0 : (P->kidx < 4 ? 1 : 2);

@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=N_READS, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--trim", default=None, help=argparse.SUPPRESS)   # e.g. tails: not the headline flags, DESIGN.md side numbers
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"], help=argparse.SUPPRESS)   # c3: 3072 specimens / 4 pools; c5: + 160-nt windows, 15 % errors
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -142,7 +143,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     lib = _lib.load()
-    args = parse_args(["specimux", pf, sf, "reads.fastq"] + (["-l", "160"] if a.config == "c5" else []))   # default flags
+    args = parse_args(["specimux", pf, sf, "reads.fastq"] + (["-l", "160"] if a.config == "c5" else []) +
+                      (["--trim", a.trim] if a.trim else []))   # default flags
     reg = sa.read_primers_file(pf)
     specimens = sa.read_specimen_file(sf, reg)
     specimens.validate()

@@ -409,7 +409,7 @@ static int ensure_device(smx_panel *P) {
     // persistent grid = exactly the resident workgroups (tiles are pulled from a queue): a workgroup that starts
     // after the queue has drained would only pay the panel staging and its one-time register spills
     {
-        const int bsv = !P->hp.bs_ok ? 0 : (P->hp.kidx < 4 ? 1 : 2);
+        const int bsv = !P->hp.bs_ok ? 0 : (P->hp.kidx < 4 ? (P->hp.trim == SMX_TRIM_TAILS ? 3 : 1) : 2);
         int occ = 0;
         if (smx_query_occupancy(P->use64, bsv, P->lds, &occ) != 0 || occ < 1) occ = 4;
         P->blocks_per_cu = occ;
@@ -448,7 +448,10 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         return SMX_OK;
     }
     // slots mode keeps one result slot per (hit, barcode): needed for the tails extent and for the parity dumps
-    const int use_slots = (P->hp.trim == SMX_TRIM_TAILS || d_hits || d_bdist || getenv("SMX_FORCE_SLOTS")) ? 1 : 0;
+    // --trim tails rides on the lean kernel when the bit-sliced scan can report the tail extent (k <= 3, at most 32
+    // barcodes per primer); otherwise, and for the parity dumps, the slots kernel keeps one result per (hit, barcode)
+    const bool lean_tails = P->hp.bs_ok && P->hp.kidx < 4 && P->hp.maxB <= 32 && !getenv("SMX_NO_LEAN_TAILS");
+    const int use_slots = ((P->hp.trim == SMX_TRIM_TAILS && !lean_tails) || d_hits || d_bdist || getenv("SMX_FORCE_SLOTS")) ? 1 : 0;
     const int R = use_slots ? P->R_slots : P->R;
     const size_t lds = use_slots ? P->lds_slots : P->lds;
     // two-kernel build only: worst case every read is deferred, one record each (grow-only)

@@ -134,7 +134,7 @@ __host__ __device__ inline int deferred_rec_bytes(int H, int MBW) {
 
 
 struct TileLayout {   // byte offsets into dynamic LDS
-    int tacc, ppeq, prpeq, bpeq, bsre, lut, pmeta, codes, namask, lens, ocnt, hits, masks, tiem, bres, dmask, ents, offsA, offsB, queue, emit, opsL, aggr,
+    int tacc, ppeq, prpeq, bpeq, bsre, lut, pmeta, codes, namask, lens, ocnt, hits, masks, tiem, bres, dmask, ents, offsA, offsB, queue, emit, opsL, aggr, etail,
         total;
     int CS;      // bytes per code row (odd number of dwords: conflict-free column reads across rows)
     int lNPs, lNBs;  // their log2
@@ -152,8 +152,10 @@ struct EntL {   // one optimal primer location of one searched hit = one barcode
     unsigned char loc_ord;  // ordinal of the location (ascending end)
     unsigned char ncol;     // target columns available (capped)
     unsigned char ok;       // 0: target empty or rejected by the prefilter rule
+    short delta;            // reference coordinate of window position j at this location = j + base - delta (bc_geom)
+    short pad;
 };
-static_assert(sizeof(EntL) == 8, "EntL layout");
+static_assert(sizeof(EntL) == 12, "EntL layout");
 
 template <typename PW>
 __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, int maxB, int need_starts,
@@ -200,6 +202,7 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
         o = (o + 15) & ~15;
         t.ents = t.opsL = o; o += c > d ? c : d;
     }
+    t.etail = o; o += (bs && !slots) ? t.CAPE * 4 : 0;   // --trim tails on the lean path: end of the kept alignment per entry
     t.masks = t.emit = o; o += R * H * MW * 4;
     t.offsA = o; o += (R * H + 1) * 4;
     t.offsB = o; o += (R * H + 1) * 4;
@@ -398,6 +401,98 @@ __device__ __forceinline__ void bitsliced_shw_pad(const unsigned *re, const unsi
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same scan for `--trim tails` (models.py:300-319): besides the distance levels it reports, for this location, the
+// minimum level of every barcode (ML[d]) and the last live column at which a barcode selected by `want` sits at its own
+// minimum -- the end of the alignment the reference keeps for that barcode (all optimal ends of its best alignment).
+// Row M, column c' corresponds to row m, column c' - (M - m): a minimum of row m travels down its diagonal for free.
+template <int KB, int M>
+__device__ __forceinline__ void bitsliced_shw_pad_tails(const unsigned *re, const unsigned char *cw, int ncol, int m,
+                                                        int kidx, const unsigned (&want)[KB + 1], unsigned (&seen)[KB + 1],
+                                                        unsigned (&ML)[KB + 1], int &tailcol) {
+    unsigned Hw[2 * KB + 1][KB + 1];
+    constexpr int WIN = 2 * KB + 1, NC = M + KB;
+    static_assert(KB < M && M <= 16, "band / padding out of range");
+    unsigned Pw[WIN], Mw[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; i++) { Pw[i] = ~0u; Mw[i] = 0u; }
+    constexpr int b0 = KB;   // D(bottom in-band row of column 0)
+    unsigned s0 = (b0 & 1) ? ~0u : 0u, s1 = (b0 & 2) ? ~0u : 0u, s2 = (b0 & 4) ? ~0u : 0u, s3 = (b0 & 8) ? ~0u : 0u,
+             s4 = 0u;
+#pragma unroll
+    for (int d = 0; d <= KB; d++) seen[d] = 0u;
+    constexpr int rs = 16;   // table block layout [row][code]: every Eq read is base + code at an immediate offset
+    const int nlive = ncol + (M - m);
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        // unconditional read (past the window it hits other LDS bytes, never out of the allocation's reach: rows are
+        // followed by >= 32 bytes of other regions) + select: no branch, so the column stays one basic block
+        const unsigned raw = (unsigned)cw[c];
+        const unsigned code = c < ncol ? raw : 15u;
+        const unsigned *rc = re + code;
+        Pw[(c + KB) % WIN] = ~0u; Mw[(c + KB) % WIN] = 0u;   // the row entering the band: initial vertical delta
+        unsigned Ph = ~0u, Mh = 0u, Zb = 0u;
+#pragma unroll
+        for (int w = 0; w < WIN; w++) {
+            const int row = c - KB + w;
+            const int sl = ((row % WIN) + WIN) % WIN;
+            if (row >= 0 && row < M) {
+                const unsigned Eq = rc[row * rs];
+                const unsigned Z = Eq | Mh | Mw[sl];
+                const unsigned nPh = Mw[sl] | ~(Z | Pw[sl]);
+                const unsigned nMh = Pw[sl] & Z;
+                const unsigned nPv = Mh | ~(Z | Ph);
+                const unsigned nMv = Ph & Z;
+                Pw[sl] = nPv; Mw[sl] = nMv; Ph = nPh; Mh = nMh;
+                Zb = Z;
+            }
+        }
+        const bool descending = c + KB <= M - 1;
+        {
+            unsigned cy = descending ? ~Zb : Ph, t;
+            t = s0 & cy; s0 ^= cy; cy = t;
+            t = s1 & cy; s1 ^= cy; cy = t;
+            t = s2 & cy; s2 ^= cy; cy = t;
+            t = s3 & cy; s3 ^= cy; cy = t;
+            s4 ^= cy;
+        }
+        if (!descending) {
+            unsigned bw = Mh, t;
+            t = ~s0 & bw; s0 ^= bw; bw = t;
+            t = ~s1 & bw; s1 ^= bw; bw = t;
+            t = ~s2 & bw; s2 ^= bw; bw = t;
+            t = ~s3 & bw; s3 ^= bw; bw = t;
+            s4 ^= bw;
+        }
+        if (c >= M - KB - 1) {   // the tracked cell sits on the last row from here on
+            const unsigned live = c < nlive ? ~0u : 0u;
+            const unsigned hi = ~(s4 | s3) & live;
+#pragma unroll
+            for (int d = 0; d <= KB; d++) {
+                const unsigned hd = hi & ((d & 1) ? s0 : ~s0) & ((d & 2) ? s1 : ~s1) & ((d & 4) ? s2 : ~s2);
+                Hw[c - (M - KB - 1)][d] = hd;
+                seen[d] |= hd;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the live ranges column-sized (otherwise ~130 LDS reads get hoisted and spill)
+    }
+    unsigned lower = 0;
+#pragma unroll
+    for (int d = 0; d <= KB; d++) {
+        ML[d] = d <= kidx ? (seen[d] & ~lower) : 0u;
+        lower |= seen[d];
+    }
+    tailcol = -1;
+#pragma unroll
+    for (int ci = 0; ci < 2 * KB + 1; ci++) {
+        unsigned any = 0;
+#pragma unroll
+        for (int d = 0; d <= KB; d++) any |= Hw[ci][d] & ML[d] & want[d];
+        tailcol = any ? (M - KB - 1) + ci - (M - m) : tailcol;   // in columns of the unpadded problem
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+
 // Scorer helpers (phase 4).  Everything is indexed, nothing is string keyed.
 // Small per-panel tables staged in LDS (the scorer and the barcode scan read them constantly).
 struct LPanel {
@@ -849,7 +944,8 @@ __device__ inline void score_general(Emitter &E, int ori) {
 
 // ------------------------------------------------------------------------------------------------
 // BSV selects the barcode scan compiled into the kernel (one variant per kernel keeps their register allocations
-// apart): 0 = per-barcode bit-vector scan only, 1 = bit-sliced, k <= 3 (padded 7-row window), 2 = bit-sliced, k 4..7.
+// apart): 0 = per-barcode bit-vector scan only, 1 = bit-sliced, k <= 3 (padded 7-row window), 2 = bit-sliced, k 4..7,
+// 3 = variant 1 + the --trim tails extent on the lean path (<= 32 barcodes per primer).
 template <typename PW, int NT, int BSV>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
 __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R,
@@ -881,6 +977,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     unsigned *bres = (unsigned *)(lds + T.bres);
     unsigned *dmask = (unsigned *)(lds + T.dmask);   // lean mode: [hit in round][distance][MBW] barcode bitmasks
     EntL *ents = (EntL *)(lds + T.ents);
+    int *etail = (int *)(lds + T.etail);     // BSV == 3 only
     int *offsA = (int *)(lds + T.offsA);    // exclusive scan of searched locations per hit
     int *offsB = (int *)(lds + T.offsB);    // exclusive scan of searched hits (rank)
     unsigned short *queue = (unsigned short *)(lds + T.queue);   // rank -> hit
@@ -1156,6 +1253,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     en.loc_ord = (unsigned char)ord;
                     en.ncol = (unsigned char)(ncol > 255 ? 255 : (ncol < 0 ? 0 : ncol));
                     en.ok = ok ? 1 : 0;
+                    en.delta = (short)bg.delta; en.pad = 0;
                     ents[e++] = en;
                     ord++;
                 }
@@ -1185,6 +1283,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 nE_pre = totE;
                 if (n > 0) {
                     queue[excl >> 16] = (unsigned short)item;
+                    if (BSV == 3) offsA[item] = (int)(excl & 0xFFFFu);   // first entry of the hit (tails pass)
                     list_entries(item, (int)(excl >> 16), (int)(excl & 0xFFFFu));
                 }
                 if (use_slots) { for (int i = tid; i < (nq << logG); i += NT) bres[i] = 0xFFFFFFFFu; }
@@ -1222,10 +1321,10 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 
         // ---- phase 3b/3c in rounds of at most CAPH searched hits and CAPE (hit, location) entries
         for (int q0 = 0; q0 < nq;) {
-            int q1, nE;
+            int q1, nE, e_base = 0;
             if (prelisted) { q1 = nq; nE = nE_pre; }
             else {
-                int e_base = offsA[queue[q0]];
+                e_base = offsA[queue[q0]];
                 if (nq - q0 <= T.CAPH && offsA[nh] - e_base <= T.CAPE) q1 = nq;   // everything left fits
                 else {
                     if (tid == 0) {
@@ -1261,11 +1360,27 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     int ei = item, w = 0;
                     if (MBW != 1) { ei = item / MBW; w = item - ei * MBW; }   // MBW == 1 (<= 32 barcodes per primer) is the usual case
                     const EntL en = ents[ei];
+                    if (BSV == 3) etail[ei] = -0x7FFFFFFF;
                     if (!en.ok) continue;
                     const int hh = en.hit, r = divH(hh), h = hh - __mul24(r, H), p = h >> 1, X = h & 1;
                     const unsigned char *cwt = codes + __mul24(r * 2 + X, CS) + en.tj0;
                     unsigned *dm = dmask + __mul24(__mul24(en.slot >> logG, kidx + 1), MBW) + w;
-                    if constexpr (BSV == 1) {
+                    if constexpr (BSV == 3) {
+                        unsigned seen[4], ML[4];
+                        const unsigned want[4] = {~0u, ~0u, ~0u, ~0u};
+                        int tc = -1;
+                        const unsigned *reb = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
+                        if (bsm == 13) bitsliced_shw_pad_tails<3, 13>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                        else if (bsm <= 8 && bsm > 3) bitsliced_shw_pad_tails<3, 8>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                        else if (bsm <= 12 && bsm > 3) bitsliced_shw_pad_tails<3, 12>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                        else bitsliced_shw_pad_tails<3, 16>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                        // end of the kept alignment in reference coordinates, valid as the hit's tail if this is its only
+                        // location (the summary redoes hits with several locations)
+                        etail[ei] = tc >= 0 ? (int)en.tj0 + tc + end_geom(lensC[r], S).base - (int)en.delta : -0x7FFFFFFF;
+#pragma unroll
+                        for (int d = 0; d < 4; d++)
+                            if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
+                    } else if constexpr (BSV == 1) {
                         unsigned seen[4];
                         // padded height: the smallest instantiated M >= barcode length (uniform branch)
                         const unsigned *reb = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
@@ -1337,6 +1452,42 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                             hl.bbest = (signed char)d; hl.ntied = (short)nt; hl.first_tied = (short)first;
                             for (int w = 0; w < MBW; w++) tiem[item * MBW + w] = dm[d * MBW + w];
                             break;
+                        }
+                    }
+                    if constexpr (BSV == 3) {
+                        // --trim tails: max over the within-k barcodes of the last optimal end of the alignment the
+                        // reference keeps for each (its FIRST location at its best distance, match_one_end :806-811)
+                        HitL &hl = hits[item];
+                        if (hl.bbest >= 0) {
+                            const int ne = hl.nloc, e0 = offsA[item] - e_base;
+                            int t = -0x7FFFFFFF;
+                            if (ne == 1) t = etail[e0];
+                            else {
+                                const int r = divH(item), h = item - __mul24(r, H), p = h >> 1, X = h & 1;
+                                const int base = end_geom(lensC[r], S).base, bsm = P->bs_m;
+                                const unsigned *reb = bsre + __mul24(p, T.BSP);   // MBW == 1 on this path
+                                unsigned GM[4], prev[4] = {0u, 0u, 0u, 0u}, lower = 0;
+#pragma unroll
+                                for (int d = 0; d < 4; d++) { GM[d] = d <= kidx ? (dm[d] & ~lower) : 0u; lower |= d <= kidx ? dm[d] : 0u; }
+                                for (int e = e0; e < e0 + ne; e++) {
+                                    const EntL en = ents[e];
+                                    if (!en.ok) continue;
+                                    unsigned want[4], seen[4], ML[4];
+#pragma unroll
+                                    for (int d = 0; d < 4; d++) want[d] = GM[d] & ~prev[d];
+                                    if (!(want[0] | want[1] | want[2] | want[3])) break;   // every barcode has its location
+                                    const unsigned char *cwt = codes + __mul24(r * 2 + X, CS) + en.tj0;
+                                    int tc = -1;
+                                    if (bsm == 13) bitsliced_shw_pad_tails<3, 13>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                                    else if (bsm <= 8 && bsm > 3) bitsliced_shw_pad_tails<3, 8>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                                    else if (bsm <= 12 && bsm > 3) bitsliced_shw_pad_tails<3, 12>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                                    else bitsliced_shw_pad_tails<3, 16>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                                    if (tc >= 0) { int v = (int)en.tj0 + tc + base - (int)en.delta; t = v > t ? v : t; }
+#pragma unroll
+                                    for (int d = 0; d < 4; d++) prev[d] |= ML[d] & GM[d];
+                                }
+                            }
+                            hl.tail_end = t;
                         }
                     }
                 }
@@ -1713,14 +1864,14 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
     if (SMX_DEFER) me = hipMemsetAsync(d_tile_counter, 0, 4 * sizeof(unsigned), s);
     if (me != hipSuccess) return (int)me;
     // one instantiation per (primer word width, barcode scan variant); slots mode never uses the bit-sliced scan
-    const int bsv = (use_slots || !P->bs_ok) ? 0 : (P->kidx < 4 ? 1 : 2);
+    const int bsv = (use_slots || !P->bs_ok) ? 0 : (P->kidx < 4 ? (P->trim == SMX_TRIM_TAILS ? 3 : 1) : 2);
 #define SMX_LAUNCH(PWT, BSVV)                                                                                         \
     hipLaunchKernelGGL((smx::demux_kernel<PWT, 256, BSVV>), dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
                        d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits, d_bdist,        \
                        d_tile_counter, use_slots, d_defer, d_tile_counter + 1)
     if (R > 64) return (int)hipErrorInvalidValue;
-    if (use64) { if (bsv == 0) SMX_LAUNCH(unsigned long long, 0); else if (bsv == 1) SMX_LAUNCH(unsigned long long, 1); else SMX_LAUNCH(unsigned long long, 2); }
-    else { if (bsv == 0) SMX_LAUNCH(unsigned, 0); else if (bsv == 1) SMX_LAUNCH(unsigned, 1); else SMX_LAUNCH(unsigned, 2); }
+    if (use64) { if (bsv == 0) SMX_LAUNCH(unsigned long long, 0); else if (bsv == 1) SMX_LAUNCH(unsigned long long, 1); else if (bsv == 2) SMX_LAUNCH(unsigned long long, 2); else SMX_LAUNCH(unsigned long long, 3); }
+    else { if (bsv == 0) SMX_LAUNCH(unsigned, 0); else if (bsv == 1) SMX_LAUNCH(unsigned, 1); else if (bsv == 2) SMX_LAUNCH(unsigned, 2); else SMX_LAUNCH(unsigned, 3); }
 #undef SMX_LAUNCH
     me = hipGetLastError();
     if (me != hipSuccess) return (int)me;
@@ -1739,10 +1890,11 @@ extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, i
 
 extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
     hipError_t e = hipSuccess;
-    const void *fns[3] = {
+    const void *fns[4] = {
         use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 0> : (const void *)smx::demux_kernel<unsigned, 256, 0>,
         use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 1> : (const void *)smx::demux_kernel<unsigned, 256, 1>,
-        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 2> : (const void *)smx::demux_kernel<unsigned, 256, 2>};
+        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 2> : (const void *)smx::demux_kernel<unsigned, 256, 2>,
+        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 3> : (const void *)smx::demux_kernel<unsigned, 256, 3>};
     for (const void *f : fns) {
         hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (r != hipSuccess) e = r;
@@ -1755,11 +1907,12 @@ extern "C" size_t smx_deferred_rec_bytes(int NP, int maxB) {   // 0: the build k
 }
 
 extern "C" int smx_query_occupancy(int use64, int bsv, size_t lds_bytes, int *blocks_per_cu) {
-    const void *fns[3] = {
+    const void *fns[4] = {
         use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 0> : (const void *)smx::demux_kernel<unsigned, 256, 0>,
         use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 1> : (const void *)smx::demux_kernel<unsigned, 256, 1>,
-        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 2> : (const void *)smx::demux_kernel<unsigned, 256, 2>};
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fns[bsv < 0 || bsv > 2 ? 0 : bsv], 256, lds_bytes);
+        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 2> : (const void *)smx::demux_kernel<unsigned, 256, 2>,
+        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 3> : (const void *)smx::demux_kernel<unsigned, 256, 3>};
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fns[bsv < 0 || bsv > 3 ? 0 : bsv], 256, lds_bytes);
 }
 
 extern "C" int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,

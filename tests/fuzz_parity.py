@@ -24,11 +24,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=6)
     ap.add_argument("--reads", type=int, default=1200)
+    ap.add_argument("--trim", default=None, help="force this trim mode onto every flag set (e.g. tails)")
     a = ap.parse_args()
     from specimux_amd import synth
     flag_sets = [dict(), dict(trim="tails"), dict(trim="primers"), dict(dereplicate="none"), dict(disable_prefilter=True),
                  dict(disable_preorient=True), dict(search_len=64), dict(search_len=120), dict(index_edit_distance=2),
                  dict(primer_edit_distance=4), dict(index_edit_distance=4, disable_prefilter=True)]
+    if a.trim:
+        flag_sets = [dict(f, trim=a.trim) for f in flag_sets if "trim" not in f]
     tmp = tempfile.mkdtemp(prefix="smx_fuzz_")
     panels = {"c2": synth.panel_c2(), "c3": synth.panel_c3(), "c1": synth.panel_c1()}
     files = {}

@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--reads", type=int, default=N_READS, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--trim", default=None, help=argparse.SUPPRESS)   # e.g. tails: not the headline flags, DESIGN.md side numbers
+    ap.add_argument("--cli-args", default="", help=argparse.SUPPRESS)  # extra specimux flags for side measurements, e.g. "-e 4"
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"], help=argparse.SUPPRESS)   # c3: 3072 specimens / 4 pools; c5: + 160-nt windows, 15 % errors
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -144,14 +145,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     lib = _lib.load()
     args = parse_args(["specimux", pf, sf, "reads.fastq"] + (["-l", "160"] if a.config == "c5" else []) +
-                      (["--trim", a.trim] if a.trim else []))   # default flags
+                      (["--trim", a.trim] if a.trim else []) + a.cli_args.split())   # default flags
     reg = sa.read_primers_file(pf)
     specimens = sa.read_specimen_file(sf, reg)
     specimens.validate()
     parameters = sa.setup_match_parameters(args, specimens)
     prefilter = BloomPrefilter(barcodes_for_bloom_prefilter(specimens), parameters.max_dist_index)
     cp = compiled_panel(specimens, parameters, args, prefilter)
-    assert parameters.max_dist_index == 3 and len(cp.specimen_ids) == (768 if a.config == "c2" else 3072)
+    assert (parameters.max_dist_index == 3 or a.cli_args) and len(cp.specimen_ids) == (768 if a.config == "c2" else 3072)
 
     n = a.reads
     d_windows = torch.from_numpy(rs.windows(cp.window_stride)).to(dev)

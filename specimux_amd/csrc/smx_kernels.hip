@@ -1393,7 +1393,15 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                             if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
                     } else if constexpr (BSV == 2) {
                         unsigned seen[8];
-                        bitsliced_shw<8>(bsre + (p * MBW + w) * T.BSP, cwt, en.ncol, bsm, kidx, seen);
+                        const unsigned *reb8 = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
+                        if (kidx == 4 && bsm > 4 && bsm <= 16) {   // k = 4: the padded straight-line scan with a 9-row window
+                            unsigned s5[5];
+                            if (bsm == 13) bitsliced_shw_pad<4, 13>(reb8, cwt, en.ncol, bsm, kidx, s5);
+                            else bitsliced_shw_pad<4, 16>(reb8, cwt, en.ncol, bsm, kidx, s5);
+#pragma unroll
+                            for (int d = 0; d < 8; d++) seen[d] = d < 5 ? s5[d] : 0u;
+                        } else
+                            bitsliced_shw<8>(reb8, cwt, en.ncol, bsm, kidx, seen);
 #pragma unroll
                         for (int d = 0; d < 8; d++)
                             if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);

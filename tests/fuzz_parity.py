@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=6)
     ap.add_argument("--reads", type=int, default=1200)
     ap.add_argument("--trim", default=None, help="force this trim mode onto every flag set (e.g. tails)")
+    ap.add_argument("--index-k", type=int, default=None, help="force this index edit distance onto every flag set")
     a = ap.parse_args()
     from specimux_amd import synth
     flag_sets = [dict(), dict(trim="tails"), dict(trim="primers"), dict(dereplicate="none"), dict(disable_prefilter=True),
@@ -32,6 +33,8 @@ def main():
                  dict(primer_edit_distance=4), dict(index_edit_distance=4, disable_prefilter=True)]
     if a.trim:
         flag_sets = [dict(f, trim=a.trim) for f in flag_sets if "trim" not in f]
+    if a.index_k is not None:
+        flag_sets = [dict(f, index_edit_distance=a.index_k) for f in flag_sets if "index_edit_distance" not in f]
     tmp = tempfile.mkdtemp(prefix="smx_fuzz_")
     panels = {"c2": synth.panel_c2(), "c3": synth.panel_c3(), "c1": synth.panel_c1()}
     files = {}

@@ -778,8 +778,20 @@ __device__ inline bool score_fast(Emitter &E, int ori) {
             if (!(t1 && t2)) return false;
             if (v.b1 && !v.b2) { rtype = SMX_R_PARTIAL_FWD; barcode = global_bc(c, v.h1, a.first_tied); }
             else if (v.b2 && !v.b1) { rtype = SMX_R_PARTIAL_REV; barcode = global_bc(c, v.h2, b.first_tied); }
+        } else if (P->derep != SMX_DEREP_BEST) {
+            // --dereplicate none: resolve_specimen's full branch (demultiplex.py:555-575) for untied barcodes --
+            // specimens_for_barcodes_and_primers in file order: one -> FULL_MATCH, several -> the first + MULTIPLE
+            if (!(t1 && t2)) return false;
+            const int g1 = global_bc(c, v.h1, a.first_tied), g2 = global_bc(c, v.h2, b.first_tied);
+            int first = -1, cnt = 0;
+            for (int sp = P->pairhead[g1 * P->NB + g2]; sp >= 0; sp = P->spec_next[sp])
+                if (((P->spec_p1m[sp] >> v.f) & 1) && ((P->spec_p2m[sp] >> v.r) & 1)) {
+                    cnt++;
+                    if (first < 0 || sp < first) first = sp;
+                }
+            if (cnt > 0) { sample = first; rtype = cnt > 1 ? SMX_R_MULTIPLE : SMX_R_FULL; pool = P->spec_pool[first]; }
+            else xflags = SMX_OPF_NO_SPECIMEN;
         } else {
-            if (P->derep != SMX_DEREP_BEST) return false;
             if (t1 && t2) {
                 int spec = specimen_exact(P, global_bc(c, v.h1, a.first_tied), global_bc(c, v.h2, b.first_tied), v.f, v.r);
                 if (spec >= 0) { sample = spec; rtype = SMX_R_DEREP_FULL; pool = P->spec_pool[spec]; }

@@ -287,20 +287,32 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     P->use64 = maxm > 32 ? 1 : 0;
     // tile size: largest R in {64, 32, ...} whose LDS image lets 4 workgroups share a CU's 160 KiB
     // (SMX_TILE_R / SMX_LDS_BUDGET override for tuning experiments)
-    size_t budget = 40 * 1024;   // 4 workgroups per CU; the k <= 3 bit-sliced kernel fits 5 (<= 96 VGPRs) when a tile needs <= 32 KiB
-    if (const char *e = getenv("SMX_LDS_BUDGET")) budget = (size_t)atol(e);
+    // Tile size: the largest R (<= 64 reads, one scorer lane per read) whose tile fits a quarter of the CU's LDS, so that
+    // four workgroups stay resident; but a tile twice as large at three workgroups per CU keeps more reads in flight
+    // (6R vs 4R) and wins for panels with many primers (measured on the 8-primer panel: R = 32 x 3 beats R = 16 x 4 by 7 %,
+    // R = 64 x 2 loses 45 %).  SMX_TILE_R / SMX_LDS_BUDGET override for tuning experiments.
+    const bool budget_forced = getenv("SMX_LDS_BUDGET") != nullptr;
+    size_t budget = 40 * 1024;
+    if (budget_forced) budget = (size_t)atol(getenv("SMX_LDS_BUDGET"));
     int rmax = 64;
     if (const char *e = getenv("SMX_TILE_R")) rmax = std::max(1, std::min(64, atoi(e)));
     const int npmeta = 5 * NP + 1 + h.n_pbc + NB + 3 * NPAIR;
-    for (int slots = 0; slots < 2; slots++)
-        for (int R = rmax; R >= 1; R >>= 1) {
-            size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, slots,
-                                              h.bs_ok);
-            if (need <= budget || R == 1) {
-                if (slots) { P->R_slots = R; P->lds_slots = need; } else { P->R = R; P->lds = need; }
-                break;
+    for (int slots = 0; slots < 2; slots++) {
+        auto pick = [&](size_t bud, int *Rout, size_t *need_out) {
+            for (int R = rmax; R >= 1; R >>= 1) {
+                size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, slots,
+                                                  h.bs_ok);
+                if (need <= bud || R == 1) { *Rout = R; *need_out = need; return; }
             }
-        }
+        };
+        int R4 = 1, R3 = 1;
+        size_t n4 = 0, n3 = 0;
+        pick(budget, &R4, &n4);
+        if (!budget_forced) pick((160 * 1024) / 3 - 512, &R3, &n3);
+        const bool three = !budget_forced && !slots && R3 > R4;   // (the slots kernel measured 2.5 % slower that way)
+        if (slots) { P->R_slots = three ? R3 : R4; P->lds_slots = three ? n3 : n4; }
+        else { P->R = three ? R3 : R4; P->lds = three ? n3 : n4; }
+    }
     if (const char *e = getenv("SMX_LDS_PAD")) P->lds += (size_t)atol(e);   // tuning experiment: residency vs LDS size
     if (P->lds > 160 * 1024 || P->lds_slots > 160 * 1024) { delete P; return fail(SMX_ERR_UNSUPPORTED, "panel needs %zu bytes of LDS per read tile", std::max(P->lds, P->lds_slots)); }
     *out = P;

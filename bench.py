@@ -225,7 +225,7 @@ def main():
     # secondary, informational: the integer-VALU issue roofline (the bound that binds).  The wave
     # instructions per launch come from the committed rocprofv3 PMC summary (SQ_INSTS_VALU) of this same workload.
     valu = None
-    ppath = os.path.join(REPO, "profiles", "r01_k_pmc_summary.json")
+    ppath = os.path.join(REPO, "profiles", "r01_l_pmc_summary.json")
     if a.config == "c2" and os.path.exists(ppath):
         with open(ppath) as fh:
             pj = json.load(fh)
@@ -234,7 +234,7 @@ def main():
             peak = 256 * 4 * 2.4e9 / 4.0          # wave64 instructions/s: 1024 SIMDs, one per 4 cycles, 2.4 GHz
             ach = insts / (avg_ms * 1e-3)
             valu = {"bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "wave64 VALU instr/s", "frac": ach / peak,
-                    "instr_per_launch": insts, "source": "profiles/r01_k_pmc_summary.json (SQ_INSTS_VALU)"}
+                    "instr_per_launch": insts, "source": "profiles/r01_l_pmc_summary.json (SQ_INSTS_VALU)"}
     matched = counts[_lib.CNT_MATCHED] / total_reads
     out = {
         "metric": "reads/sec demultiplexed, 768-specimen ITS panel on 765k ONT-style reads",

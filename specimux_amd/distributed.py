@@ -38,20 +38,34 @@ class CountsReducer:
         self.comm = C.c_void_p()
         if world > 1 and backend == "rccl":
             import sys
+            import torch
             import torch.distributed as dist
-            from . import _lib
-            lib = _lib.load()
+            # Every step below is collective-safe: rank 0 always broadcasts (the id or None), and the ranks agree by an
+            # all-reduce on whether everybody can go on -- a failure on one rank must not leave the others waiting.
+            lib = None
+            payload = None
             try:
-                uid = (C.c_uint8 * 128)()
+                from . import _lib
+                lib = _lib.load()
                 if rank == 0:
+                    uid = (C.c_uint8 * 128)()
                     _lib.check(lib.smx_comm_unique_id(uid))
-                box = [bytes(uid)]
-                dist.broadcast_object_list(box, src=0)
+                    payload = bytes(uid)
+            except Exception as e:
+                print(f"[specimux_amd] rank {rank}: C-ABI RCCL communicator unavailable ({e})", file=sys.stderr)
+                lib = None
+            box = [payload]
+            dist.broadcast_object_list(box, src=0)
+            ready = torch.tensor([1 if (lib is not None and box[0] is not None) else 0], dtype=torch.int32,
+                                 device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+            if int(ready.item()) == 1:
+                from . import _lib
                 uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
                 _lib.check(lib.smx_comm_init(uid, world, rank, C.byref(self.comm)))
-            except Exception as e:   # same collective through torch.distributed's RCCL communicator instead
-                print(f"[specimux_amd] C-ABI RCCL communicator unavailable ({e}); using torch.distributed all_reduce",
-                      file=sys.stderr)
+            else:   # the same collective through torch.distributed's RCCL communicator instead
+                if rank == 0:
+                    print("[specimux_amd] using torch.distributed all_reduce for the counts", file=sys.stderr)
                 self.comm = C.c_void_p()
                 self.backend = "torch"
 

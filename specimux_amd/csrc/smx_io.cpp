@@ -123,6 +123,10 @@ struct smx_reader {
     int fd = -1;
     uint64_t fsize = 0, fpos = 0;
     bool fast = false;
+    // ---- fast engine on gzip input: inflate a block, then parse it in parallel
+    bool gzfast = false, gz_eof = false;
+    std::vector<char> carry;
+    uint64_t upos = 0;
 
     bool next_line(const char **p, size_t *n) {
         for (;;) {
@@ -307,6 +311,76 @@ bool parse_strict(const char *base, const char *p, const char *stop, const char 
     return true;
 }
 
+// Parse one in-memory block of strict FASTQ with all I/O threads.  Returns 1 = records placed in `b` and *next_off =
+// offset of the first unconsumed byte; 0 = irregular input (the general engine must take over from the block start);
+// 2 = no complete record in the block (caller retries with a bigger block); 3 = nothing but white space up to the
+// end of the input.
+int parse_block(const std::shared_ptr<Blob> &block, uint64_t len, bool last_block, uint32_t max_reads, smx_batch *b,
+                uint64_t *next_off_out) {
+    const char *base = block->data(), *end = base + len;
+    const int T = io_threads();
+    std::vector<const char *> cut(T + 1);
+    cut[0] = base;
+    cut[T] = end;
+    for (int t = 1; t < T; t++) {
+        const char *nominal = base + len * (uint64_t)t / (uint64_t)T;
+        const char *ls = nominal;   // back up to a line start
+        while (ls > base && ls[-1] != '\n') ls--;
+        cut[t] = find_record_start(ls, end);
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    }
+    std::vector<std::vector<Rec>> parts(T);
+    std::vector<const char *> stopped(T, nullptr);
+    std::vector<char> ok(T, 1);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+            if (cut[t] >= cut[t + 1]) { stopped[t] = cut[t]; return; }
+            ok[t] = parse_strict(base, cut[t], cut[t + 1], end, last_block, parts[t], &stopped[t]) ? 1 : 0;
+        });
+    for (auto &x : th) x.join();
+    for (int t = 0; t < T; t++) if (!ok[t]) return 0;
+    // parts must chain exactly (every cut is a genuine record start); only the part holding the block's last
+    // record may stop early, at the start of a record the block end cuts in two
+    const char *consumed = end;
+    bool tail_open = false;
+    for (int t = 0; t < T; t++) {
+        if (cut[t] >= cut[t + 1]) continue;
+        if (tail_open) { if (!parts[t].empty()) return 0; continue; }
+        if (stopped[t] == cut[t + 1]) continue;
+        if (stopped[t] < cut[t + 1]) { consumed = stopped[t]; tail_open = true; }
+        else return 0;
+    }
+    uint64_t total = 0;
+    for (auto &v : parts) total += v.size();
+    if (total == 0) {
+        if (last_block) {   // trailing blank lines / garbage: let the general engine judge it
+            for (const char *c = base; c < end; c++) if (!is_space((unsigned char)*c)) return 0;
+            return 3;
+        }
+        return 2;           // one record larger than the block
+    }
+    // keep at most max_reads records
+    uint64_t keep = std::min<uint64_t>(total, max_reads);
+    uint64_t next_off = (uint64_t)(consumed - base);
+    b->block = block;
+    uint64_t seen = 0;
+    for (int t = 0; t < T && seen < keep; t++) {
+        if (parts[t].empty()) continue;
+        uint64_t take = std::min<uint64_t>(parts[t].size(), keep - seen);
+        if (take < parts[t].size()) { next_off = parts[t][take].src_off; parts[t].resize(take); }
+        else if (seen + take == keep && keep < total) {
+            for (int u = t + 1; u < T; u++) if (!parts[u].empty()) { next_off = parts[u][0].src_off; break; }
+        }
+        b->segs.emplace_back();
+        b->segs.back().base = base;
+        b->segs.back().recs = std::move(parts[t]);
+        seen += take;
+    }
+    *next_off_out = next_off;
+    return 1;
+}
+
 // Returns 1 = batch filled by the fast engine, 0 = irregular input: caller must use the general engine from fpos.
 int next_fast(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batch *b) {
     if (r->fpos >= r->fsize) return 1;   // end of file: empty batch
@@ -346,70 +420,42 @@ int next_fast(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batch *
             if (got_t[t] < hi - lo) break;   // short read: the file ends here
         }
         if (got < len) { len = got; last_block = true; block->resize(len); }
-        const char *base = block->data(), *end = base + len;
-        const int T = io_threads();
-        std::vector<const char *> cut(T + 1);
-        cut[0] = base;
-        cut[T] = end;
-        for (int t = 1; t < T; t++) {
-            const char *nominal = base + len * (uint64_t)t / (uint64_t)T;
-            const char *ls = nominal;   // back up to a line start
-            while (ls > base && ls[-1] != '\n') ls--;
-            cut[t] = find_record_start(ls, end);
-            if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
-        }
-        std::vector<std::vector<Rec>> parts(T);
-        std::vector<const char *> stopped(T, nullptr);
-        std::vector<char> ok(T, 1);
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; t++)
-            th.emplace_back([&, t] {
-                if (cut[t] >= cut[t + 1]) { stopped[t] = cut[t]; return; }
-                ok[t] = parse_strict(base, cut[t], cut[t + 1], end, last_block, parts[t], &stopped[t]) ? 1 : 0;
-            });
-        for (auto &x : th) x.join();
-        for (int t = 0; t < T; t++) if (!ok[t]) return 0;
-        // parts must chain exactly (every cut is a genuine record start); only the part holding the block's last
-        // record may stop early, at the start of a record the block end cuts in two
-        const char *consumed = end;
-        bool tail_open = false;
-        for (int t = 0; t < T; t++) {
-            if (cut[t] >= cut[t + 1]) continue;
-            if (tail_open) { if (!parts[t].empty()) return 0; continue; }
-            if (stopped[t] == cut[t + 1]) continue;
-            if (stopped[t] < cut[t + 1]) { consumed = stopped[t]; tail_open = true; }
-            else return 0;
-        }
-        uint64_t total = 0;
-        for (auto &v : parts) total += v.size();
-        if (total == 0) {
-            if (last_block) {   // trailing blank lines / garbage: let the general engine judge it
-                bool blank = true;
-                for (const char *c = base; c < end; c++) if (!is_space((unsigned char)*c)) { blank = false; break; }
-                if (blank) { r->fpos = r->fsize; return 1; }
-                return 0;
-            }
-            want *= 2;          // one record larger than the block: retry with a bigger block
-            continue;
-        }
-        // keep at most max_reads records
-        uint64_t keep = std::min<uint64_t>(total, max_reads);
-        uint64_t next_off = (uint64_t)(consumed - base);
-        b->block = block;
-        uint64_t seen = 0;
-        for (int t = 0; t < T && seen < keep; t++) {
-            if (parts[t].empty()) continue;
-            uint64_t take = std::min<uint64_t>(parts[t].size(), keep - seen);
-            if (take < parts[t].size()) { next_off = parts[t][take].src_off; parts[t].resize(take); }
-            else if (seen + take == keep && keep < total) {
-                for (int u = t + 1; u < T; u++) if (!parts[u].empty()) { next_off = parts[u][0].src_off; break; }
-            }
-            b->segs.emplace_back();
-            b->segs.back().base = base;
-            b->segs.back().recs = std::move(parts[t]);
-            seen += take;
-        }
+        uint64_t next_off = 0;
+        int rc = parse_block(block, len, last_block, max_reads, b, &next_off);
+        if (rc == 0) return 0;
+        if (rc == 3) { r->fpos = r->fsize; return 1; }
+        if (rc == 2) { want *= 2; continue; }
         r->fpos += next_off;
+        return 1;
+    }
+}
+
+// gzip input: one thread inflates a block (zlib is a single stream), then all I/O threads parse it -- the general
+// engine would do both serially.  `carry` holds the inflated bytes after the last complete record of the previous block;
+// upos is the uncompressed offset of carry[0] (where the general engine resumes if the input turns out irregular).
+int next_fast_gz(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batch *b) {
+    uint64_t want = max_bytes ? std::min<uint64_t>(max_bytes, 96ull << 20) : (96ull << 20);
+    want = std::min<uint64_t>(want, (uint64_t)max_reads * 4096 + (1u << 20));
+    for (;;) {
+        if (r->gz_eof && r->carry.empty()) return 1;   // end of input: empty batch
+        auto block = std::make_shared<Blob>(r->carry.size() + want);
+        if (!block->data()) { smx_set_error(SMX_ERR_ARG, "out of memory reading %s", r->path.c_str()); return -1; }
+        if (!r->carry.empty()) memcpy(block->data(), r->carry.data(), r->carry.size());
+        uint64_t len = r->carry.size();
+        while (!r->gz_eof && len < r->carry.size() + want) {
+            int got = gzread(r->gz, block->data() + len, (unsigned)std::min<uint64_t>(r->carry.size() + want - len, 1u << 30));
+            if (got < 0) { smx_set_error(SMX_ERR_ARG, "read %s: gzip stream error", r->path.c_str()); return -1; }
+            if (got == 0) { r->gz_eof = true; break; }
+            len += (uint64_t)got;
+        }
+        block->resize(len);
+        uint64_t next_off = 0;
+        int rc = parse_block(block, len, r->gz_eof, max_reads, b, &next_off);
+        if (rc == 0) return 0;
+        if (rc == 3) { r->carry.clear(); r->upos += len; return 1; }
+        if (rc == 2) { r->carry.assign(block->data(), block->data() + len); want *= 2; continue; }
+        r->carry.assign(block->data() + next_off, block->data() + len);
+        r->upos += next_off;
         return 1;
     }
 }
@@ -640,6 +686,13 @@ int smx_reader_open(const char *path, smx_reader **out, int *is_fastq) {
             r->fast = true;
         } else if (fd >= 0) close(fd);
     }
+    if (r->fastq && !r->fast && gzdirect(gz) == 0 && !getenv("SMX_IO_SERIAL")) {
+        // gzip stream: what peek() has already inflated becomes the first carry
+        r->carry.assign(r->buf.data() + r->pos, r->buf.data() + r->end);
+        r->upos = 0;
+        r->gz_eof = r->eof;
+        r->gzfast = true;
+    }
     if (is_fastq) *is_fastq = r->fastq ? 1 : 0;
     *out = r;
     return SMX_OK;
@@ -675,6 +728,19 @@ int smx_reader_next(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_b
     b->clear();
     *n_read = 0;
     if (max_reads == 0) return SMX_OK;
+    if (r->gzfast) {
+        int rc = next_fast_gz(r, max_reads, max_bytes, b);
+        if (rc < 0) return SMX_ERR_ARG;
+        if (rc == 0) {   // irregular FASTQ: the general engine continues from the uncompressed offset of this block
+            b->clear();
+            r->gzfast = false;
+            r->carry.clear();
+            if (gzseek(r->gz, (z_off_t)r->upos, SEEK_SET) < 0)
+                return smx_set_error(SMX_ERR_ARG, "cannot seek in %s", r->path.c_str());
+            r->pos = r->end = 0;
+            r->eof = false;
+        }
+    }
     if (r->fast) {
         int rc = next_fast(r, max_reads, max_bytes, b);
         if (rc < 0) return SMX_ERR_ARG;
@@ -687,7 +753,7 @@ int smx_reader_next(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_b
             r->eof = false;
         }
     }
-    if (!r->fast) {
+    if (!r->fast && !r->gzfast) {
         int rc = next_general(r, max_reads, max_bytes, b);
         if (rc) return rc;
     }

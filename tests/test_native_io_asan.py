@@ -65,6 +65,11 @@ def test_io_under_sanitizers(driver, tmp_path):
                      f"{lines[i]}\n{s}\n+\n{q}\n")
         fh.write("\n")
     assert _run(driver, str(wrapped), tmp_path / "owr", 4, 5) == expect
+    # the same irregular file gzip-compressed: inflate-then-parallel-parse must fall back through gzseek
+    wgz = tmp_path / "wrapped.fastq.gz"
+    with open(wrapped, "rb") as src, gzip.open(wgz, "wb") as dst:
+        dst.write(src.read())
+    assert _run(driver, str(wgz), tmp_path / "owgz", 5, 3) == expect
     # FASTA
     fa = tmp_path / "reads.fasta"
     with open(fa, "w") as fh:

@@ -177,8 +177,10 @@ int smx_pack_windows(const uint8_t *bases, const uint64_t *offsets, uint32_t n_r
  *   d_counts       smx_counts_len() uint64, accumulated into (not cleared)
  *   d_hits/d_bdist optional parity dumps (NULL to skip): n_reads*smx_hits_per_read() smx_hit and
  *                  n_reads*smx_bdist_per_read() int8 best distance per (read, primer, end, barcode slot), -1 none
- * Launches on one panel must be ordered (same stream, or externally serialised): a panel owns one tile queue.
- * Use one panel per concurrent stream.
+ *                  d_bdist selects the per-barcode ("slots") kernel; d_hits alone is filled by whichever kernel the
+ *                  panel's flags select (tail_end is then defined only under --trim tails)
+ * Launches on one stream are ordered; a panel keeps one tile queue per stream it is launched on (at most 16
+ * streams), so double-buffered callers may overlap launches of one panel on different streams.
  */
 int smx_batch_run_device(const smx_panel *panel, void *stream, const uint8_t *d_windows, const int32_t *d_lens,
                          uint32_t n_reads, smx_op *d_ops, smx_op *d_extra, uint32_t extra_cap,

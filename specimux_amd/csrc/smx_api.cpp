@@ -94,6 +94,8 @@ size_t blob_add(std::vector<unsigned char> &blob, const std::vector<T> &v) {
 
 }  // namespace
 
+#define SMX_MAX_STREAMS 16   // distinct streams one panel may be launched on
+
 struct DevBuf {   // grow-only device buffer of the host-buffer convenience path
     void *p = nullptr;
     size_t cap = 0;
@@ -126,8 +128,12 @@ struct smx_panel {
     int blocks_per_cu = 1, blocks_per_cu_slots = 1;   // resident workgroups per CU: lean / slots kernel
     std::mutex ws_mutex;                     // smx_batch_run is serialised per panel (one workspace)
     DevBuf ws[8];                            // windows, lens, ops, extra, n_extra, counts, hits, bdist
-    DevBuf defer;                            // hit-table dumps of the reads deferred to the general scorer
-    unsigned *d_tile_counter = nullptr;      // {tile queue head, deferred reads, finished workgroups, extra records}: self re-arming
+    // Launch counters {tile queue head, -, finished workgroups, extra records}, 64 bytes per slot, self re-arming.
+    // One slot per stream the panel has been launched on: launches on one stream are ordered, launches on different
+    // streams (double-buffered pipelines) each pull tiles from their own queue.
+    unsigned *d_tile_counter = nullptr;
+    std::mutex tc_mutex;
+    std::vector<void *> tc_streams;
     unsigned long long *d_phase = nullptr;   // SMX_PHASE_TIMING diagnostic
     int phase_grid = 0;
 };
@@ -314,7 +320,11 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
         else { P->R = three ? R3 : R4; P->lds = three ? n3 : n4; }
     }
     if (const char *e = getenv("SMX_LDS_PAD")) P->lds += (size_t)atol(e);   // tuning experiment: residency vs LDS size
-    if (P->lds > 160 * 1024 || P->lds_slots > 160 * 1024) { delete P; return fail(SMX_ERR_UNSUPPORTED, "panel needs %zu bytes of LDS per read tile", std::max(P->lds, P->lds_slots)); }
+    if (P->lds > 160 * 1024 || P->lds_slots > 160 * 1024) {
+        const size_t need = std::max(P->lds, P->lds_slots);
+        delete P;
+        return fail(SMX_ERR_UNSUPPORTED, "panel needs %zu bytes of LDS per read tile", need);
+    }
     *out = P;
     return SMX_OK;
 }
@@ -357,7 +367,6 @@ void smx_panel_destroy(smx_panel *P) {
     if (P->d_blob) (void)hipFree(P->d_blob);
     if (P->d_tile_counter) (void)hipFree(P->d_tile_counter);
     for (auto &b : P->ws) b.release();
-    P->defer.release();
     delete P;
 }
 
@@ -397,8 +406,8 @@ static int ensure_device(smx_panel *P) {
     P->n_cu = prop.multiProcessorCount;
     HIP_TRY(hipMalloc(&P->d_blob, P->blob.size()));
     HIP_TRY(hipMemcpy(P->d_blob, P->blob.data(), P->blob.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void **)&P->d_tile_counter, 64));
-    HIP_TRY(hipMemset(P->d_tile_counter, 0, 64));   // the kernel re-arms these counters itself after every launch
+    HIP_TRY(hipMalloc((void **)&P->d_tile_counter, 64 * SMX_MAX_STREAMS));
+    HIP_TRY(hipMemset(P->d_tile_counter, 0, 64 * SMX_MAX_STREAMS));   // the kernel re-arms these counters itself after every launch
     unsigned char *b = (unsigned char *)P->d_blob;
     smx::DevPanel &h = P->hp;
     h.ppeq = (const unsigned long long *)(b + P->o_ppeq);
@@ -459,23 +468,29 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
             return fail(SMX_ERR_DEVICE, "cannot clear the extra-record counter");
         return SMX_OK;
     }
-    // slots mode keeps one result slot per (hit, barcode): needed for the tails extent and for the parity dumps
-    // --trim tails rides on the lean kernel when the bit-sliced scan can report the tail extent (k <= 3, at most 32
-    // barcodes per primer); otherwise, and for the parity dumps, the slots kernel keeps one result per (hit, barcode)
+    // slots mode keeps one result slot per (hit, barcode): needed for the per-barcode distance dump (d_bdist) and for
+    // --trim tails when the bit-sliced scan cannot report the tail extent (it can for k <= 3 and at most 32 barcodes
+    // per primer).  The hit dump alone (d_hits) comes from whichever kernel the flags select, so that the parity tests
+    // see the hit table of the kernel that is benchmarked; its tail_end is defined only where that kernel computes it.
     const bool lean_tails = P->hp.bs_ok && P->hp.kidx < 4 && P->hp.maxB <= 32 && !getenv("SMX_NO_LEAN_TAILS");
-    const int use_slots = ((P->hp.trim == SMX_TRIM_TAILS && !lean_tails) || d_hits || d_bdist || getenv("SMX_FORCE_SLOTS")) ? 1 : 0;
+    const int use_slots = ((P->hp.trim == SMX_TRIM_TAILS && !lean_tails) || d_bdist || getenv("SMX_FORCE_SLOTS")) ? 1 : 0;
     const int R = use_slots ? P->R_slots : P->R;
     const size_t lds = use_slots ? P->lds_slots : P->lds;
-    // two-kernel build only: worst case every read is deferred, one record each (grow-only)
-    if (smx_deferred_rec_bytes(P->hp.NP, P->hp.maxB) > 0) {
-        hipError_t de = P->defer.ensure((size_t)n_reads * smx_deferred_rec_bytes(P->hp.NP, P->hp.maxB));
-        if (de != hipSuccess) return fail(SMX_ERR_DEVICE, "deferred-read buffer: %s", hipGetErrorString(de));
+    unsigned *tc = nullptr;
+    {
+        std::lock_guard<std::mutex> g(P->tc_mutex);
+        size_t i = 0;
+        while (i < P->tc_streams.size() && P->tc_streams[i] != stream) i++;
+        if (i == P->tc_streams.size()) {
+            if (i == SMX_MAX_STREAMS) return fail(SMX_ERR_UNSUPPORTED, "one panel launched on more than %d streams", SMX_MAX_STREAMS);
+            P->tc_streams.push_back(stream);
+        }
+        tc = P->d_tile_counter + 16 * i;
     }
     uint32_t tiles = (n_reads + R - 1) / R;
     int grid = (int)std::min<uint32_t>(tiles, (uint32_t)(P->n_cu * (use_slots ? P->blocks_per_cu_slots : P->blocks_per_cu)));
     int e = smx_launch_demux(&P->hp, P->use64, R, grid, lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
-                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, P->d_tile_counter, use_slots,
-                             (unsigned char *)P->defer.p);
+                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, use_slots);
     if (e != 0) return fail(SMX_ERR_DEVICE, "demux kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return SMX_OK;
 }
@@ -511,11 +526,12 @@ int smx_batch_run(const smx_panel *Pc, const uint8_t *windows, const int32_t *le
     rc = smx_batch_run_device(P, nullptr, dw, (const int32_t *)dl, n_reads, (smx_op *)dop, (smx_op *)dex, extra_cap,
                               (uint32_t *)dn, (uint64_t *)dc, (smx_hit *)dh, (int8_t *)db);
     if (rc) return rc;
-    TRY_C(hipDeviceSynchronize());
-    if (getenv("SMX_DEBUG")) {
-        unsigned tc[2] = {0, 0};
-        (void)hipMemcpy(tc, P->d_tile_counter, 8, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[smx] batch of %u reads: %u deferred to the general scorer\n", n_reads, tc[1]);
+    {
+        hipError_t se = hipDeviceSynchronize();
+        if (se != hipSuccess) {   // an aborted launch leaves the self re-arming counters in an unknown state
+            (void)hipMemset(P->d_tile_counter, 0, 64 * SMX_MAX_STREAMS);
+            return fail(SMX_ERR_DEVICE, "demux kernel failed: %s", hipGetErrorString(se));
+        }
     }
     std::vector<uint64_t> c(ncnt);
     TRY_C(hipMemcpy(ops, dop, (size_t)n_reads * sizeof(smx_op), hipMemcpyDeviceToHost));
@@ -526,6 +542,13 @@ int smx_batch_run(const smx_panel *Pc, const uint8_t *windows, const int32_t *le
     if (hits) TRY_C(hipMemcpy(hits, dh, hbytes, hipMemcpyDeviceToHost));
     if (bdist) TRY_C(hipMemcpy(bdist, db, bbytes, hipMemcpyDeviceToHost));
 #undef TRY_C
+    if (c[SMX_CNT_TOTAL] != n_reads) {
+        // every read is counted exactly once by the tile that scored it: anything else means tiles were skipped or
+        // repeated (a tile queue that did not start at zero) and the records above cannot be trusted
+        (void)hipMemset(P->d_tile_counter, 0, 64 * SMX_MAX_STREAMS);
+        return fail(SMX_ERR_DEVICE, "demux kernel processed %llu of %u reads (tile queue out of step); counters reset",
+                    (unsigned long long)c[SMX_CNT_TOTAL], n_reads);
+    }
     for (size_t i = 0; i < ncnt; i++) counts[i] += c[i];
     if (c[SMX_CNT_OVERFLOW]) return fail(SMX_ERR_OVERFLOW, "%llu read(s) produced more than 16 write operations",
                                          (unsigned long long)c[SMX_CNT_OVERFLOW]);

@@ -49,8 +49,7 @@ extern "C" {
 int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t lds_bytes, void *stream,
                      const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops, smx_op *d_extra,
                      uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts, smx_hit *d_hits, int8_t *d_bdist,
-                     unsigned *d_tile_counter, int use_slots, unsigned char *d_defer);
-size_t smx_deferred_rec_bytes(int NP, int maxB);
+                     unsigned *d_tile_counter, int use_slots);
 size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta, int kidx,
                            int slots, int bs);
 int smx_set_demux_lds_limit(int use64, size_t bytes);

@@ -127,6 +127,21 @@ struct smx_reader {
     bool gzfast = false, gz_eof = false;
     std::vector<char> carry;
     uint64_t upos = 0;
+    bool gz_failed = false;   // sticky: a gzread error or a stream that ends inside a gzip member
+    std::string gz_msg;
+
+    // gzread returned <= 0: a clean end of input only if zlib reports no error AND is at end of file.  A corrupt
+    // stream gives -1 (Z_DATA_ERROR); a truncated one gives 0 with Z_BUF_ERROR -- Python's gzip raises on both
+    // (EOFError / BadGzipFile, what the reference's open_sequence_file sees), so neither may pass as end of file.
+    bool clean_eof(int got) {
+        int errnum = Z_OK;
+        const char *msg = gzerror(gz, &errnum);
+        if (got == 0 && (errnum == Z_OK || errnum == Z_STREAM_END) && gzeof(gz)) return true;
+        gz_failed = true;
+        gz_msg = (errnum == Z_BUF_ERROR || errnum == Z_OK) ? "unexpected end of compressed stream"
+                                                          : (msg && *msg ? msg : "gzip stream error");
+        return false;
+    }
 
     bool next_line(const char **p, size_t *n) {
         for (;;) {
@@ -141,7 +156,7 @@ struct smx_reader {
             if (pos > 0) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
             if (end == buf.size()) buf.resize(buf.size() * 2);
             int got = gzread(gz, buf.data() + end, (unsigned)std::min<size_t>(buf.size() - end, 1u << 30));
-            if (got <= 0) eof = true; else end += (size_t)got;
+            if (got <= 0) { (void)clean_eof(got); eof = true; } else end += (size_t)got;
         }
     }
     int peek() {
@@ -150,7 +165,7 @@ struct smx_reader {
             if (eof) return -1;
             pos = end = 0;
             int got = gzread(gz, buf.data(), (unsigned)buf.size());
-            if (got <= 0) eof = true; else end = (size_t)got;
+            if (got <= 0) { (void)clean_eof(got); eof = true; } else end = (size_t)got;
         }
     }
 };
@@ -444,8 +459,11 @@ int next_fast_gz(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batc
         uint64_t len = r->carry.size();
         while (!r->gz_eof && len < r->carry.size() + want) {
             int got = gzread(r->gz, block->data() + len, (unsigned)std::min<uint64_t>(r->carry.size() + want - len, 1u << 30));
-            if (got < 0) { smx_set_error(SMX_ERR_ARG, "read %s: gzip stream error", r->path.c_str()); return -1; }
-            if (got == 0) { r->gz_eof = true; break; }
+            if (got <= 0) {
+                if (!r->clean_eof(got)) { smx_set_error(SMX_ERR_ARG, "read %s: %s", r->path.c_str(), r->gz_msg.c_str()); return -1; }
+                r->gz_eof = true;
+                break;
+            }
             len += (uint64_t)got;
         }
         block->resize(len);
@@ -676,6 +694,12 @@ int smx_reader_open(const char *path, smx_reader **out, int *is_fastq) {
     r->fastq = fmt == 1;
     // fast engine: uncompressed FASTQ only (gzdirect() is 1 when zlib is passing the bytes through)
     (void)r->peek();
+    if (r->gz_failed) {
+        int rc = smx_set_error(SMX_ERR_ARG, "read %s: %s", path, r->gz_msg.c_str());
+        gzclose(gz);
+        delete r;
+        return rc;
+    }
     if (r->fastq && !compressed_name && gzdirect(gz) == 1 && !getenv("SMX_IO_SERIAL")) {
         int fd = open(path, O_RDONLY);
         struct stat st;
@@ -755,6 +779,8 @@ int smx_reader_next(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_b
     }
     if (!r->fast && !r->gzfast) {
         int rc = next_general(r, max_reads, max_bytes, b);
+        // a stream error wins over whatever the parser made of the truncated tail
+        if (r->gz_failed) { b->clear(); return smx_set_error(SMX_ERR_ARG, "read %s: %s", r->path.c_str(), r->gz_msg.c_str()); }
         if (rc) return rc;
     }
     b->finish();

@@ -119,20 +119,6 @@ struct HitL {
 static_assert(sizeof(HitL) == 16, "HitL layout");
 
 #define SMX_MAX_EMIT 16
-// SMX_DEFER=1 builds the two-kernel variant: the hot kernel dumps the hit table of reads that need the general
-// scorer (ties, several best candidates) and score_deferred_kernel finishes them.  Measured on MI355X: the hot
-// kernel gets 10 % shorter but the deferred kernel is one long dependent chain of global loads (0.25 ms for 0.1 %
-// of the reads), so the single-kernel build (0) is the default.
-#ifndef SMX_DEFER
-#define SMX_DEFER 0
-#endif
-
-// Deferred reads (general scorer): record = int read, L, ori, pad; HitL hits[H]; unsigned tiem[H * MBW]
-__host__ __device__ inline int deferred_rec_bytes(int H, int MBW) {
-    return (16 + H * (int)sizeof(HitL) + H * MBW * 4 + 15) & ~15;
-}
-
-
 struct TileLayout {   // byte offsets into dynamic LDS
     int tacc, ppeq, prpeq, bpeq, bsre, lut, pmeta, codes, namask, lens, ocnt, hits, masks, tiem, bres, dmask, ents, offsA, offsB, queue, emit, opsL, aggr, etail,
         total;
@@ -730,8 +716,8 @@ __device__ inline bool cand_has_specimen(const ReadCtx &c, const CandView &v, in
 
 // Fast scorer of the hot kernel: handles "no candidate" and "exactly one candidate at the best score, no
 // barcode tie".  Every dereplication group then has one member and the reference's machinery reduces to a
-// single emission.  Returns false for everything else (several best candidates, ties): those reads are
-// deferred to score_deferred_kernel, which runs score_general on a dump of the read's hit table.
+// single emission.  Returns false for everything else (several best candidates, ties): the caller then runs
+// score_general, the reference's selection / dereplication in full, for that read.
 __device__ inline bool score_fast(Emitter &E, int ori) {
     const ReadCtx &c = *E.c;
     const DevPanel *P = c.P;
@@ -829,7 +815,7 @@ __device__ inline bool score_fast(Emitter &E, int ori) {
     return true;
 }
 
-// General scorer (deferred kernel only): the reference's selection / dereplication in full.
+// General scorer: the reference's selection / dereplication in full (reads score_fast declines, ~0.1 %).
 __device__ inline void score_general(Emitter &E, int ori) {
     const ReadCtx &c = *E.c;
     const DevPanel *P = c.P;
@@ -964,8 +950,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
                                                     unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist,
-                                                    unsigned *tile_counter, int use_slots, unsigned char *defer_recs,
-                                                    unsigned *n_deferred) {
+                                                    unsigned *tile_counter, int use_slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
     const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
@@ -1631,7 +1616,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
                     Emitter E;
                     E.c = &c; E.primary = opsL + r; E.extra = extra; E.extra_cap = extra_cap;
-                    E.n_extra = SMX_DEFER ? n_extra : tile_counter + 3;   // see the kernel's epilogue
+                    E.n_extra = tile_counter + 3;   // see the kernel's epilogue
                     E.counts = counts; E.emitlog = emitlog + r * SMX_MAX_EMIT; E.aggr = aggr; E.read = r0 + r;
                     E.n = 0; E.matched = false; E.overflow = false;
                     if (score_fast(E, ori)) {
@@ -1639,27 +1624,12 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                         if (E.matched) atomicAdd(&aggr[1], 1);
                         if (E.n > 1) atomicAdd(&aggr[6], 1);
                         if (E.overflow) atomicAdd(&aggr[7], 1);
-                    } else if (!SMX_DEFER) {
+                    } else {
                         score_general(E, ori);
                         opsL[r].n_ops = (uint16_t)E.n;
                         if (E.matched) atomicAdd(&aggr[1], 1);
                         if (E.n > 1) atomicAdd(&aggr[6], 1);
                         if (E.overflow) atomicAdd(&aggr[7], 1);
-                    } else {
-                        // rare: ties or several best candidates -> dump this read's hit table for the general scorer
-                        unsigned slot = atomicAdd(n_deferred, 1u);
-                        unsigned char *rec = defer_recs + (size_t)slot * deferred_rec_bytes(H, MBW);
-                        int *hdr = (int *)rec;
-                        hdr[0] = (int)(r0 + r); hdr[1] = L; hdr[2] = ori; hdr[3] = 0;
-                        HitL *dh = (HitL *)(rec + 16);
-                        for (int h = 0; h < H; h++) dh[h] = hits[r * H + h];
-                        unsigned *dt = (unsigned *)(rec + 16 + H * sizeof(HitL));
-                        for (int w = 0; w < H * MBW; w++) dt[w] = tiem[r * H * MBW + w];
-                        smx_op op;   // placeholder: the deferred kernel overwrites ops[read]
-                        op.sample = -1; op.trim_start = 0; op.trim_end = 0; op.pool = -1; op.p1 = op.p2 = -1; op.barcode = -1;
-                        op.dist[0] = op.dist[1] = op.dist[2] = op.dist[3] = -1;
-                        op.rtype = SMX_R_UNKNOWN; op.flags = 0; op.n_ops = 0; op.read = r0 + r;
-                        opsL[r] = op;
                     }
                 }
             }
@@ -1781,59 +1751,18 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 #undef STAMP
     // block aggregates -> global counters
     if (tid < 8 && aggr[tid]) atomicAdd(&counts[tid], (unsigned long long)aggr[tid]);
-    // The launch counters re-arm themselves: tile_counter = {tile queue head, deferred reads, finished workgroups,
-    // extra records}.  The last workgroup to get here publishes the extra-record count and zeroes the block, so a launch
+    // The launch counters re-arm themselves: tile_counter = {tile queue head, -, finished workgroups, extra records}.  The last workgroup to get here publishes the extra-record count and zeroes the block, so a launch
     // needs no memset in front of it (two small fills per batch were ~2 % of a 0.4 ms launch).
-    if (!SMX_DEFER) {
-        __syncthreads();
-        if (tid == 0) {
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const unsigned prev = atomicAdd(tile_counter + 2, 1u);
+        if (prev == gridDim.x - 1) {
             __threadfence();
-            const unsigned prev = atomicAdd(tile_counter + 2, 1u);
-            if (prev == gridDim.x - 1) {
-                __threadfence();
-                *n_extra = atomicAdd(tile_counter + 3, 0u);
-                tile_counter[0] = 0; tile_counter[2] = 0; tile_counter[3] = 0;
-            }
+            *n_extra = atomicAdd(tile_counter + 3, 0u);
+            tile_counter[0] = 0; tile_counter[2] = 0; tile_counter[3] = 0;
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Deferred reads.  Record layout in global memory (fixed size per panel, 16-byte aligned):
-//   int read, L, ori, pad;  HitL hits[H];  unsigned tiem[H * MBW]
-__global__ __launch_bounds__(64) void score_deferred_kernel(DevPanel Pv, const unsigned char *recs,
-                                                            const unsigned *n_deferred, smx_op *ops, smx_op *extra,
-                                                            uint32_t extra_cap, uint32_t *n_extra,
-                                                            unsigned long long *counts) {
-    __shared__ int aggr[12];
-    const DevPanel *P = &Pv;
-    const int H = 2 * P->NP, MBW = (P->maxB + 31) / 32, rb = deferred_rec_bytes(H, MBW);
-    if (threadIdx.x < 12) aggr[threadIdx.x] = 0;
-    __syncthreads();
-    const unsigned nd = *n_deferred;
-    for (unsigned i = blockIdx.x * 64 + threadIdx.x; i < nd; i += gridDim.x * 64) {
-        const unsigned char *rec = recs + (size_t)i * rb;
-        const int *hdr = (const int *)rec;
-        unsigned emitlog[SMX_MAX_EMIT];
-        ReadCtx c;
-        c.P = P;
-        c.LP.pm = P->pm; c.LP.pk = P->pk; c.LP.pdir = P->pdir; c.LP.pfidx = P->pfidx; c.LP.pbc_off = P->pbc_off;
-        c.LP.pbc = P->pbc; c.LP.bm = P->bm; c.LP.pair_f = P->pair_f; c.LP.pair_r = P->pair_r; c.LP.pair_pool = P->pair_pool;
-        c.hits = (const HitL *)(rec + 16);
-        c.tiem = (const unsigned *)(rec + 16 + H * sizeof(HitL));
-        c.MBW = MBW; c.L = hdr[1]; c.S = P->S; c.g = end_geom(hdr[1], P->S);
-        Emitter E;
-        E.c = &c; E.primary = ops + hdr[0]; E.extra = extra; E.extra_cap = extra_cap; E.n_extra = n_extra;
-        E.counts = counts; E.emitlog = emitlog; E.aggr = aggr; E.read = (unsigned)hdr[0];
-        E.n = 0; E.matched = false; E.overflow = false;
-        score_general(E, hdr[2]);
-        ops[hdr[0]].n_ops = (uint16_t)E.n;
-        if (E.matched) atomicAdd(&aggr[1], 1);
-        if (E.n > 1) atomicAdd(&aggr[6], 1);
-        if (E.overflow) atomicAdd(&aggr[7], 1);
-    }
-    __syncthreads();
-    if (threadIdx.x < 8 && aggr[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)aggr[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1875,30 +1804,20 @@ __global__ void align_kernel(const unsigned long long *peq, const unsigned long 
 extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t lds_bytes, void *stream,
                                 const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops,
                                 smx_op *d_extra, uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts,
-                                smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter, int use_slots,
-                                unsigned char *d_defer) {
+                                smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter, int use_slots) {
     hipStream_t s = (hipStream_t)stream;
-    // d_tile_counter = {tile queue head, deferred reads, finished workgroups, extra records}: zero at allocation, re-armed by
-    // the last workgroup of every launch (the two-kernel build still clears it here)
-    hipError_t me = hipSuccess;
-    if (SMX_DEFER) me = hipMemsetAsync(d_tile_counter, 0, 4 * sizeof(unsigned), s);
-    if (me != hipSuccess) return (int)me;
+    // d_tile_counter = {tile queue head, -, finished workgroups, extra records}: zero at allocation, re-armed by
+    // the last workgroup of every launch
     // one instantiation per (primer word width, barcode scan variant); slots mode never uses the bit-sliced scan
     const int bsv = (use_slots || !P->bs_ok) ? 0 : (P->kidx < 4 ? (P->trim == SMX_TRIM_TAILS ? 3 : 1) : 2);
 #define SMX_LAUNCH(PWT, BSVV)                                                                                         \
     hipLaunchKernelGGL((smx::demux_kernel<PWT, 256, BSVV>), dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
                        d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits, d_bdist,        \
-                       d_tile_counter, use_slots, d_defer, d_tile_counter + 1)
+                       d_tile_counter, use_slots)
     if (R > 64) return (int)hipErrorInvalidValue;
     if (use64) { if (bsv == 0) SMX_LAUNCH(unsigned long long, 0); else if (bsv == 1) SMX_LAUNCH(unsigned long long, 1); else if (bsv == 2) SMX_LAUNCH(unsigned long long, 2); else SMX_LAUNCH(unsigned long long, 3); }
     else { if (bsv == 0) SMX_LAUNCH(unsigned, 0); else if (bsv == 1) SMX_LAUNCH(unsigned, 1); else if (bsv == 2) SMX_LAUNCH(unsigned, 2); else SMX_LAUNCH(unsigned, 3); }
 #undef SMX_LAUNCH
-    me = hipGetLastError();
-    if (me != hipSuccess) return (int)me;
-    // general scorer over the deferred reads (usually well under 1 %): ordered after the main kernel on the stream
-    if (SMX_DEFER)
-    hipLaunchKernelGGL(smx::score_deferred_kernel, dim3(512), dim3(64), 0, s, *P, d_defer, d_tile_counter + 1, d_ops, d_extra,
-                       extra_cap, d_n_extra, (unsigned long long *)d_counts);
     return (int)hipGetLastError();
 }
 
@@ -1920,10 +1839,6 @@ extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
         if (r != hipSuccess) e = r;
     }
     return (int)e;
-}
-
-extern "C" size_t smx_deferred_rec_bytes(int NP, int maxB) {   // 0: the build keeps the general scorer inline
-    return SMX_DEFER ? (size_t)smx::deferred_rec_bytes(2 * NP, (maxB + 31) / 32) : 0;
 }
 
 extern "C" int smx_query_occupancy(int use64, int bsv, size_t lds_bytes, int *blocks_per_cu) {

@@ -79,9 +79,13 @@ class CountsReducer:
                                                         C.c_void_p(stream_ptr) if stream_ptr else None))
         else:
             import torch.distributed as dist
-            if stream_ptr:   # counts were produced on a side stream: make the collective's stream see them
+            if stream_ptr and counts.is_cuda:
+                # counts were produced on `stream_ptr`: the collective runs on torch's current stream, which must wait
+                # for the PRODUCING stream (not for itself)
                 import torch
-                torch.cuda.current_stream().synchronize()
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.ExternalStream(stream_ptr))
+                torch.cuda.current_stream().wait_event(ev)
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         return counts
 

@@ -162,14 +162,16 @@ class CompiledPanel:
         return windows, lens
 
     def run(self, windows: np.ndarray, lens: np.ndarray, counts=None, want_hits=False):
-        """Host-buffer convenience path (smx_batch_run): returns (ops, extra, counts[, hits, bdist])."""
+        """Host-buffer convenience path (smx_batch_run): returns (ops, extra, counts[, hits, bdist]).
+        want_hits=True asks for the hit table AND the per-barcode distances (per-barcode "slots" kernel);
+        want_hits="lean" asks for the hit table only, from the kernel the flags select (bdist is None)."""
         n = len(lens)
         ops = np.zeros(n, dtype=_lib.OP_DTYPE)
         cap = max(64, n // 4)
         if counts is None:
             counts = np.zeros(self.counts_len, dtype=np.uint64)
         hits = np.zeros((n, self.hits_per_read), dtype=_lib.HIT_DTYPE) if want_hits else None
-        bdist = np.zeros((n, self.hits_per_read, self.max_barcodes), dtype=np.int8) if want_hits else None
+        bdist = np.zeros((n, self.hits_per_read, self.max_barcodes), dtype=np.int8) if want_hits is True else None
         while True:
             extra = np.zeros(cap, dtype=_lib.OP_DTYPE)
             n_extra = C.c_uint32(0)

@@ -191,6 +191,13 @@ FLAG_SETS = [
     dict(index_edit_distance=2, primer_edit_distance=4), dict(index_edit_distance=5),
     dict(search_len=40), dict(search_len=120), dict(search_len=256), dict(min_length=300, max_length=900),
     dict(trim="tails", dereplicate="none", disable_preorient=True, disable_prefilter=True),
+    # k = 4 selects the 9-row padded bit-sliced scan (demux_kernel<u32,256,2> / bitsliced_shw_pad<4,13>), k = 6, 7 the
+    # generic banded one (bitsliced_shw<8>); search_len 50 / 81 / 1..3 leave the unrolled primer loop ((S & 3) != 0)
+    # and the 16-byte encode path ((S & 15) != 0)
+    dict(index_edit_distance=4), dict(index_edit_distance=6), dict(index_edit_distance=7),
+    dict(index_edit_distance=4, trim="tails"), dict(index_edit_distance=7, trim="primers", dereplicate="none"),
+    dict(search_len=50), dict(search_len=81), dict(search_len=81, trim="tails"), dict(search_len=3), dict(search_len=2),
+    dict(search_len=1),
 ]
 
 
@@ -468,10 +475,14 @@ def _custom_panel(tmp_path_factory, name, n_fwd, n_rev, bc_len, min_dist, fwd_pr
 
 
 @pytest.mark.parametrize("shape", ["96x4_multiword", "24nt_barcodes", "40nt_primer_64bit", "mixed_lengths",
-                                   "8nt_barcodes", "10nt_barcodes", "16nt_barcodes"])
+                                   "8nt_barcodes", "10nt_barcodes", "16nt_barcodes", "16nt_barcodes_k4",
+                                   "16nt_barcodes_k6", "8nt_barcodes_k4", "96x4_multiword_k5"])
 def test_panel_shapes(lib, tmp_path_factory, shape):
     from specimux_amd import synth
     flags = {}
+    if "_k" in shape:   # bitsliced_shw_pad<4,16> (16 nt, k = 4), the generic scan at other heights / word counts
+        flags = dict(index_edit_distance=int(shape.rsplit("_k", 1)[1]))
+        shape = shape.rsplit("_k", 1)[0]
     if shape == "96x4_multiword":      # > 64 barcodes on one primer: 3-word tie masks, G = 128 slots
         pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 96, 4, 13, 5)
     elif shape == "24nt_barcodes":     # longer than the bit-sliced path's 16 rows: per-barcode lean path, larger k

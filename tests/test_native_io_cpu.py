@@ -64,6 +64,38 @@ def test_reader_formats(tmp_path):
         _all_records(os.fspath(bad))
 
 
+@pytest.mark.parametrize("engine", ["parallel", "serial"])
+@pytest.mark.parametrize("kind", ["fastq", "fasta"])
+def test_reader_rejects_truncated_and_corrupt_gzip(tmp_path, monkeypatch, kind, engine):
+    """A gzip stream that ends inside a member, or fails its integrity check, is an error (the reference's gzip
+    module raises EOFError / BadGzipFile in open_sequence_file): never a short but 'successful' read."""
+    from specimux_amd import _lib
+    if engine == "serial":
+        monkeypatch.setenv("SMX_IO_SERIAL", "1")
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(4000):
+        s = "".join("ACGT"[c] for c in rng.integers(0, 4, 300))
+        recs.append(f"@r{i}\n{s}\n+\n{'I' * 300}\n" if kind == "fastq" else f">r{i}\n{s[:150]}\n{s[150:]}\n")
+    raw = gzip.compress("".join(recs).encode(), 6)
+    good = tmp_path / f"good.{kind}.gz"
+    good.write_bytes(raw)
+    got, _fq = _all_records(os.fspath(good), chunk=1500)
+    assert len(got) == 4000
+    cut = tmp_path / f"cut.{kind}.gz"
+    cut.write_bytes(raw[: len(raw) * 2 // 3])                     # truncated mid-stream
+    flipped = bytearray(raw)
+    for k in range(len(raw) // 2, len(raw) // 2 + 8):
+        flipped[k] ^= 0x5A                                       # corrupt deflate data mid-stream
+    flip = tmp_path / f"flip.{kind}.gz"
+    flip.write_bytes(bytes(flipped))
+    notrailer = tmp_path / f"notrailer.{kind}.gz"
+    notrailer.write_bytes(raw[:-6])                               # only the CRC/size trailer is incomplete
+    for bad in (cut, flip, notrailer):
+        with pytest.raises(_lib.SmxError):
+            _all_records(os.fspath(bad), chunk=1500)
+
+
 def test_pack_windows_batch_equals_pack_windows():
     from specimux_amd.demultiplex import compiled_panel, concat_records
     from specimux_amd.io_utils import SeqRecord

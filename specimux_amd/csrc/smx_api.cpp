@@ -15,6 +15,7 @@
 
 #include "smx.h"
 #include "smx_internal.h"
+#include "smx_prescan_core.h"
 
 namespace {
 
@@ -134,6 +135,13 @@ struct smx_panel {
     unsigned *d_tile_counter = nullptr;
     std::mutex tc_mutex;
     std::vector<void *> tc_streams;
+    // primer prescan (smx_prescan.hip): bit-sliced HW alignment of every primer over both end windows, run in front of
+    // the demux kernel, which then only redoes the alignments the prescan cannot take (smx_prescan_core.h)
+    bool pre_ok = false;
+    smx::PreDesc pre;
+    int pre_nw = 2, pre_mr = 24, pre_nx = 0, pre_blocks_per_cu = 1;
+    size_t pre_lds = 0;
+    DevBuf pre_recs[SMX_MAX_STREAMS];        // per stream slot: [2 * NP][n_reads rounded up to a tile] PreRec
     unsigned long long *d_phase = nullptr;   // SMX_PHASE_TIMING diagnostic
     int phase_grid = 0;
 };
@@ -215,6 +223,27 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
         maxB = std::max(maxB, (int)(d->primer_bc_off[p + 1] - d->primer_bc_off[p]));
     }
     pbc_off[NP] = (int)d->primer_bc_off[NP];
+    {   // prescan description: the searched patterns as A/C/G/T sets per row
+        std::vector<std::string> pats(NP);
+        std::vector<const char *> pp(NP);
+        std::vector<int> pl(NP);
+        for (int p = 0; p < NP; p++) {
+            pats[p].assign(d->primer_rc + d->primer_rc_off[p], d->primer_rc_off[p + 1] - d->primer_rc_off[p]);
+            pp[p] = pats[p].c_str();
+            pl[p] = (int)pats[p].size();
+        }
+        memset(&P->pre, 0, sizeof(P->pre));
+        P->pre_ok = maxm <= smx::PRE_MAXROWS && !getenv("SMX_NO_PRESCAN") &&
+                    smx::prescan_build_desc(&P->pre, NP, h.S, pp.data(), pl.data(), pk.data(),
+                                            [](unsigned char a, unsigned char b) { return a < 128 && b < 128 && eqt().eq[a][b]; });
+        if (P->pre_ok) {
+            P->pre_mr = maxm;
+            P->pre_nx = P->pre.nsym - 4;
+            P->pre_nw = NP >= 4 ? 4 : 2;   // wave w aligns primers w, w + nw, ...
+            P->pre_lds = smx_prescan_lds_bytes(h.S, P->pre.nsym, P->pre_nw);
+            if (P->pre_lds > 160 * 1024) P->pre_ok = false;
+        }
+    }
     if (maxB > 1024) { delete P; return fail(SMX_ERR_UNSUPPORTED, "more than 1024 barcodes on one primer (%d)", maxB); }
     std::vector<int> pbc(std::max(pbc_off[NP], 1));
     for (int i = 0; i < pbc_off[NP]; i++) {
@@ -367,6 +396,7 @@ void smx_panel_destroy(smx_panel *P) {
     if (P->d_blob) (void)hipFree(P->d_blob);
     if (P->d_tile_counter) (void)hipFree(P->d_tile_counter);
     for (auto &b : P->ws) b.release();
+    for (auto &b : P->pre_recs) b.release();
     delete P;
 }
 
@@ -438,6 +468,13 @@ static int ensure_device(smx_panel *P) {
         if (smx_query_occupancy(P->use64, 0, P->lds_slots, &occ) != 0 || occ < 1) occ = 4;
         P->blocks_per_cu_slots = occ;
     }
+    if (P->pre_ok) {
+        if (P->pre_lds > 64 * 1024 && smx_prescan_set_lds_limit(P->pre_nw, P->pre_mr, P->pre_nx, P->pre_lds) != 0)
+            return fail(SMX_ERR_DEVICE, "cannot raise the prescan kernel's dynamic LDS limit to %zu bytes", P->pre_lds);
+        int occ = 0;
+        if (smx_prescan_occupancy(P->pre_nw, P->pre_mr, P->pre_nx, P->pre_lds, &occ) != 0 || occ < 1) occ = 1;
+        P->pre_blocks_per_cu = occ;
+    }
     if (const char *e = getenv("SMX_BLOCKS_PER_CU")) P->blocks_per_cu = P->blocks_per_cu_slots = std::max(1, atoi(e));
     if (getenv("SMX_DEBUG")) {
         int occ = -1;
@@ -477,20 +514,39 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     const int R = use_slots ? P->R_slots : P->R;
     const size_t lds = use_slots ? P->lds_slots : P->lds;
     unsigned *tc = nullptr;
+    size_t slot = 0;
     {
         std::lock_guard<std::mutex> g(P->tc_mutex);
-        size_t i = 0;
-        while (i < P->tc_streams.size() && P->tc_streams[i] != stream) i++;
-        if (i == P->tc_streams.size()) {
-            if (i == SMX_MAX_STREAMS) return fail(SMX_ERR_UNSUPPORTED, "one panel launched on more than %d streams", SMX_MAX_STREAMS);
+        while (slot < P->tc_streams.size() && P->tc_streams[slot] != stream) slot++;
+        if (slot == P->tc_streams.size()) {
+            if (slot == SMX_MAX_STREAMS) return fail(SMX_ERR_UNSUPPORTED, "one panel launched on more than %d streams", SMX_MAX_STREAMS);
             P->tc_streams.push_back(stream);
         }
-        tc = P->d_tile_counter + 16 * i;
+        tc = P->d_tile_counter + 16 * slot;
+    }
+    // primer prescan in front of the demux kernel (same stream: ordered)
+    const smx::PreRec *d_pre = nullptr;
+    uint32_t npad = 0;
+    if (P->pre_ok) {
+        npad = (n_reads + smx::PRE_TILE - 1) / smx::PRE_TILE * smx::PRE_TILE;
+        const size_t need = (size_t)2 * P->hp.NP * npad * sizeof(smx::PreRec);
+        DevBuf &pb = P->pre_recs[slot];
+        if (need > pb.cap) {
+            if (pb.p) (void)hipStreamSynchronize((hipStream_t)stream);   // earlier launches on this stream still read it
+            hipError_t pe = pb.ensure(need);
+            if (pe != hipSuccess) return fail(SMX_ERR_DEVICE, "prescan record buffer: %s", hipGetErrorString(pe));
+        }
+        const uint32_t ptiles = npad / smx::PRE_TILE;
+        const int pgrid = (int)std::min<uint32_t>(ptiles, (uint32_t)(P->n_cu * P->pre_blocks_per_cu));
+        int pe = smx_launch_prescan(&P->pre, P->pre_nw, P->pre_mr, P->pre_nx, pgrid, P->pre_lds, stream, d_windows, n_reads,
+                                    P->hp.wstride, (smx::PreRec *)pb.p, npad);
+        if (pe != 0) return fail(SMX_ERR_DEVICE, "prescan kernel launch failed: %s", hipGetErrorString((hipError_t)pe));
+        d_pre = (const smx::PreRec *)pb.p;
     }
     uint32_t tiles = (n_reads + R - 1) / R;
     int grid = (int)std::min<uint32_t>(tiles, (uint32_t)(P->n_cu * (use_slots ? P->blocks_per_cu_slots : P->blocks_per_cu)));
     int e = smx_launch_demux(&P->hp, P->use64, R, grid, lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
-                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, use_slots);
+                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, use_slots, d_pre, npad);
     if (e != 0) return fail(SMX_ERR_DEVICE, "demux kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return SMX_OK;
 }

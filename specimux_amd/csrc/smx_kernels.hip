@@ -120,7 +120,7 @@ static_assert(sizeof(HitL) == 16, "HitL layout");
 
 #define SMX_MAX_EMIT 16
 struct TileLayout {   // byte offsets into dynamic LDS
-    int tacc, ppeq, prpeq, bpeq, bsre, lut, pmeta, codes, namask, lens, ocnt, hits, masks, tiem, bres, dmask, ents, offsA, offsB, queue, emit, opsL, aggr, etail,
+    int tacc, ppeq, prpeq, bpeq, bsre, lut, pmeta, codes, namask, lens, ocnt, rflag, hits, masks, tiem, bres, dmask, ents, offsA, offsB, queue, emit, opsL, aggr, etail,
         total;
     int CS;      // bytes per code row (odd number of dwords: conflict-free column reads across rows)
     int lNPs, lNBs;  // their log2
@@ -178,6 +178,7 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.namask = o; o += R * 2 * MW * 4;         // per code row: bit j set = code[j] is not A/C/G/T
     t.lens = o;  o += 2 * R * 4;               // double-buffered: the next tile is encoded while this one is scored
     t.ocnt = o;  o += 2 * R * 4;               // per read: forward votes | reverse votes << 16; double-buffered
+    t.rflag = o; o += 2 * R * 4;               // per read: 1 = the prescan cannot speak for it (short / non-ACGT window); double-buffered
     t.hits = o;  o += R * H * (int)sizeof(HitL);
     t.tiem = o;  o += R * H * t.MBW * 4;
     // time-shared regions: {location entries} are dead after the barcode scan -> staged result records;
@@ -950,7 +951,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
                                                     unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist,
-                                                    unsigned *tile_counter, int use_slots) {
+                                                    unsigned *tile_counter, int use_slots,
+                                                    const PreRec *__restrict__ pre, uint32_t npad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
     const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
@@ -968,6 +970,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     unsigned *namask = (unsigned *)(lds + T.namask);
     int *lensL = (int *)(lds + T.lens);
     int *ocnt = (int *)(lds + T.ocnt);
+    int *rflag = (int *)(lds + T.rflag);
     HitL *hits = (HitL *)(lds + T.hits);
     unsigned *masks = (unsigned *)(lds + T.masks);
     unsigned *tiem = (unsigned *)(lds + T.tiem);
@@ -1056,6 +1059,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         const int nr = have ? (int)((n_reads - r0) < (uint32_t)R ? (n_reads - r0) : (uint32_t)R) : 0;
         const int nh = nr * H;
         int *lensC = lensL + par * R, *ocntC = ocnt + par * R;
+        const int *rflagC = rflag + par * R;
         if (timing) tacc[10] = clock64();
         if (have) {
         // ---- phase 2: primer scan, one lane per (read, primer, end)
@@ -1072,7 +1076,26 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 #if defined(SMX_EXP) && SMX_EXP == 7
             g.Sp = 0; g.j_lo = 1;   // timing experiment: no primer columns
 #endif
-            if (sizeof(PW) == 4 && g.j_lo == 0 && g.Sp == S && (S & 3) == 0) {
+            // the prescan kernel has aligned this primer over this window already (bit-sliced over 32 reads,
+            // smx_prescan_core.h) unless the read is short or holds anything but upper-case ACGT, or the optimal ends
+            // spread too far for its record: those alignments are (re)done by the scalar scan below
+            bool pre_done = false;
+            if (pre != nullptr && rflagC[r] == 0) {
+                const uint2 rec = ((const uint2 *)pre)[(size_t)h * npad + r0 + (uint32_t)r];
+                if (!(rec.x >> 31)) {
+                    pre_done = true;
+                    const int pb = (int)(rec.x & 0xFFu);
+                    unsigned long long bits = 0;
+                    if (pb != 0xFF) {
+                        best = pb; jstar = (int)((rec.x >> 8) & 0xFFu); cnt = __popc(rec.y);
+                        bits = (unsigned long long)rec.y << (jstar & 31);
+                    }
+                    for (int w = 0; w < MW; w++)
+                        mrow[w] = w == (jstar >> 5) ? (unsigned)bits : (w == (jstar >> 5) + 1 ? (unsigned)(bits >> 32) : 0u);
+                }
+            }
+            if (pre_done) {
+            } else if (sizeof(PW) == 4 && g.j_lo == 0 && g.Sp == S && (S & 3) == 0) {
                 // common case (full window, 32-bit patterns): eight columns per unrolled block, one byte read per
                 // column (cheaper than unpacking a dword of codes: tools/ubench/primer_col.hip), uniform trip counts;
                 // the "new minimum" / "above minimum" flags are funnel-shifted into bit-reversed words
@@ -1585,7 +1608,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         }   // have
         // the encode target buffers: namask is OR-ed into, the next tile's orientation votes are counted up
         for (int i = tid; i < R * 2 * MW; i += NT) namask[i] = 0;
-        for (int i = tid; i < R; i += NT) ocnt[(par ^ 1) * R + i] = 0;
+        for (int i = tid; i < R; i += NT) { ocnt[(par ^ 1) * R + i] = 0; rflag[(par ^ 1) * R + i] = 0; }
         __syncthreads();
         const uint32_t nxt = (uint32_t)aggr[9];
         STAMP(0);
@@ -1698,6 +1721,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 #pragma unroll
                         for (int q = 0; q < 4; q++) dst[tail ? 4 * c + q : S4 - 1 - (4 * c + q)] = pk[q];
                     } else {
+                        rflag[(par ^ 1) * R + r] = 1;   // short read or a non-ACGT byte: the scalar primer scan takes this read
                         encode_bytes(r, L, (tail ? S : 0) + 16 * c, v);
                     }
                 }
@@ -1804,7 +1828,8 @@ __global__ void align_kernel(const unsigned long long *peq, const unsigned long 
 extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t lds_bytes, void *stream,
                                 const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops,
                                 smx_op *d_extra, uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts,
-                                smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter, int use_slots) {
+                                smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter, int use_slots,
+                                const smx::PreRec *d_pre, uint32_t npad) {
     hipStream_t s = (hipStream_t)stream;
     // d_tile_counter = {tile queue head, -, finished workgroups, extra records}: zero at allocation, re-armed by
     // the last workgroup of every launch
@@ -1813,7 +1838,7 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
 #define SMX_LAUNCH(PWT, BSVV)                                                                                         \
     hipLaunchKernelGGL((smx::demux_kernel<PWT, 256, BSVV>), dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
                        d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits, d_bdist,        \
-                       d_tile_counter, use_slots)
+                       d_tile_counter, use_slots, d_pre, npad)
     if (R > 64) return (int)hipErrorInvalidValue;
     if (use64) { if (bsv == 0) SMX_LAUNCH(unsigned long long, 0); else if (bsv == 1) SMX_LAUNCH(unsigned long long, 1); else if (bsv == 2) SMX_LAUNCH(unsigned long long, 2); else SMX_LAUNCH(unsigned long long, 3); }
     else { if (bsv == 0) SMX_LAUNCH(unsigned, 0); else if (bsv == 1) SMX_LAUNCH(unsigned, 1); else if (bsv == 2) SMX_LAUNCH(unsigned, 2); else SMX_LAUNCH(unsigned, 3); }

@@ -1,0 +1,307 @@
+// smx_prescan_core.h -- the primer prescan ("K_A"): Myers-equivalent HW (infix) alignment of every primer against both
+// end windows of every read, BIT-SLICED ACROSS READS: one lane aligns one primer against one end of 32 reads at once
+// (bit r of every word belongs to read r of the lane's 32-read group).  Replaces the per-(read, primer, end) bit-vector
+// scan of the demux kernel for the common case -- full-length windows of upper-case A/C/G/T -- at ~1/4 of its VALU
+// work: 5 three-input bit-ops per DP cell serve 32 reads, against ~22 instructions per text column per read.
+// Reads the scan cannot take (shorter than search_len, any other character in a window) and alignments whose optimal
+// ends spread over more than 16 columns are redone by the demux kernel's scalar scan; its results are bit-identical
+// (reference: match_one_end demultiplex.py:755-770, align_seq alignment.py:21-50, edlib HW mode).
+//
+// This header is host/device code: the kernel (smx_prescan.hip) and the CPU unit test (tests/cpu/prescan_sim.cpp) run
+// the same functions; on the host a "lane" is a loop index and LDS is a plain array.
+//
+// Per tile of PRE_G x 32 reads (one workgroup):
+//   phase 1  coalesced 16-byte loads of the windows; 16 ASCII bases -> one dword of 2-bit codes ((ch >> 1) & 3:
+//            A 0, C 1, T 2, G 3; 8 VALU per 16 bases), stored as 32 x 32 bit blocks [group][16-column chunk][read]
+//   phase 2  in-place 32 x 32 bit transposes: word (column, plane) over the 32 reads of the group; end A blocks (the
+//            head window) are stored reversed and complemented: the DP then sees revcomp(head) like the scalar scan
+//   phase 3  DP: lane = (group, end), primer uniform per wave.  Per column: the four base-occurrence words (and the
+//            unions a degenerate primer letter needs) go to a per-lane LDS scratch; row i reads its Eq word from a
+//            precomputed address (the pattern letter selects the scratch row): no per-cell select instruction.
+//            Unit-cost cell on the vertical / horizontal deltas (5 bit-ops), HW boundaries (top row free).
+//            Last-row bookkeeping: gap = score - running minimum as a 5-plane bit-sliced counter;
+//            lt = "new minimum here", e = "at the minimum here" -- two flag words per column.
+//            Every 16 columns the 16 lt + 16 e words are transposed back (one 32 x 32 transpose) and folded into the
+//            per-read state: number of minima so far (best = m - count), column of the last one (= first column at the
+//            final minimum: jstar), and the e flags of the 16 columns from jstar on (relmask).
+//   phase 4  one 8-byte record per (read, primer, end): best distance (or "no match within k"), jstar, relmask.
+#ifndef SMX_PRESCAN_CORE_H
+#define SMX_PRESCAN_CORE_H
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define SMX_HD __host__ __device__ __forceinline__
+#else
+#define SMX_HD inline
+#endif
+
+namespace smx {
+
+constexpr int PRE_G = 32;          // 32-read groups per tile: one wave = 32 groups x 2 ends
+constexpr int PRE_TILE = PRE_G * 32;
+constexpr int PRE_MAXROWS = 31;    // primers up to 31 nt (5-plane gap counter)
+constexpr int PRE_MAXSYM = 8;      // distinct pattern letters (as A/C/G/T sets) per panel
+constexpr int PRE_BLK = 33;        // dwords per 32 x 32 bit block in LDS (odd: conflict-free column access)
+constexpr int PRE_SCRATCH = 2 * (PRE_MAXSYM + 1) * 64;   // dwords of per-wave scratch: [2 buffers][symbol][lane]
+
+// Record layout: meta bits 0-7 = best distance (0xFF: no match within k), 8-15 = jstar, bit 31 = the optimal ends
+// spread beyond jstar + 15 (redo with the scalar scan); relmask bit i (< 16) = column jstar + i is an optimal end.
+struct PreRec { uint32_t meta, relmask; };
+
+// Host-built description of the patterns (device copy passed by value to the kernel).
+struct PreDesc {
+    int NP, S, nsym, pure4;        // pure4: symbols 0..3 are exactly {A}, {C}, {T}, {G}
+    uint8_t m[64], k[64];
+    uint8_t symmask[PRE_MAXSYM];   // bit0 A, bit1 C, bit2 T, bit3 G (2-bit text code order)
+    uint8_t sym[64][32];           // pattern letter of row i of primer p, as a symbol index
+};
+
+// out[r] bit q = in[q] bit r
+SMX_HD void transpose32(unsigned (&a)[32]) {
+#define SMX_TSTAGE(J, MASK)                                                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < 32; k_++) if ((k_ & J) == 0) {                     \
+        const unsigned t_ = ((a[k_] >> J) ^ a[k_ + J]) & MASK;                                 \
+        a[k_ + J] ^= t_;                                                                       \
+        a[k_] ^= t_ << J;                                                                      \
+    }
+    SMX_TSTAGE(16, 0x0000FFFFu)
+    SMX_TSTAGE(8, 0x00FF00FFu)
+    SMX_TSTAGE(4, 0x0F0F0F0Fu)
+    SMX_TSTAGE(2, 0x33333333u)
+    SMX_TSTAGE(1, 0x55555555u)
+#undef SMX_TSTAGE
+}
+
+// 16 ASCII bases (four little-endian dwords) -> 32 bits: byte i, bit pair kq <-> base 4 * kq + i; code = (ch >> 1) & 3
+SMX_HD unsigned pack16(unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+    unsigned z = (w0 >> 1) & 0x03030303u;
+    z |= (w1 << 1) & 0x0C0C0C0Cu;
+    z |= (w2 << 3) & 0x30303030u;
+    z |= (w3 << 5) & 0xC0C0C0C0u;
+    return z;
+}
+// bit q of a packed dword belongs to base t of the chunk, plane (code bit) pl
+SMX_HD int pack_t(int q) { return 4 * ((q & 7) >> 1) + (q >> 3); }
+SMX_HD int pack_pl(int q) { return q & 1; }
+
+// ---- per-read fold of one 16-column chunk: w = lt flags (bits 0-15) | e flags (bits 16-31), column 16 * ch + t at bit t.
+// One state word per read (the fold state of a lane's 32 reads lives in registers): bits 0-15 relmask, 16-20 number of
+// minima so far, 21-28 column of the last one, bit 31 overflow (an optimal end at or beyond jstar + PRE_RELBITS).
+constexpr int PRE_RELBITS = 16;
+SMX_HD void fold16(unsigned w, int ch, unsigned &st) {
+    const unsigned lt16 = w & 0xFFFFu, e16 = w >> 16;
+    const int col0 = 16 * ch;
+    if (lt16) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int last = 31 - __clz((int)lt16);
+        const int pc = __popc(lt16);
+#else
+        const int last = 31 - __builtin_clz(lt16);
+        const int pc = __builtin_popcount(lt16);
+#endif
+        st = (e16 >> last) | ((((st >> 16) & 31u) + (unsigned)pc) << 16) | ((unsigned)(col0 + last) << 21);
+    } else {
+        int sh = col0 - (int)((st >> 21) & 0xFFu);
+        if (sh > 16) sh = 16;
+        const unsigned v = e16 << sh;   // bits that leave the 16-bit window mean "optimal end too far from jstar"
+        st |= (v & 0xFFFFu) | ((v >> 16) ? 0x80000000u : 0u);
+    }
+}
+
+SMX_HD PreRec make_rec(unsigned st, int m, int k) {
+    PreRec r;
+    const int best = m - (int)((st >> 16) & 31u);
+    if (best <= k) { r.meta = (unsigned)best | (((st >> 21) & 0xFFu) << 8) | (st & 0x80000000u); r.relmask = st & 0xFFFFu; }
+    else { r.meta = 0xFFu; r.relmask = 0; }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phase 1, one 16-byte piece: piece q of the tile = (read q / ppr, piece c = q % ppr of its window row); ppr = pieces per
+// read = 2 * S / 16.  `w` = the four dwords of the piece.  Block (g, c) holds the packed dwords of the group's 32 reads.
+SMX_HD void prescan_store_piece(unsigned *planes, int read_in_tile, int c, int ppr, unsigned w0, unsigned w1, unsigned w2,
+                                unsigned w3) {
+    const int g = read_in_tile >> 5, rr = read_in_tile & 31;
+    planes[(g * ppr + c) * PRE_BLK + rr] = pack16(w0, w1, w2, w3);
+}
+
+// Phase 2, one block: transpose in place into DP order.  Pieces c < CH are the head window (end A: stored reversed and
+// complemented), pieces c >= CH the tail window (end B).  DP order: word 2 * t' + plane for DP column t' of the chunk.
+SMX_HD void prescan_transpose_block(unsigned *planes, int blk, int c, int CH) {
+    unsigned a[32];
+    unsigned *pb = planes + blk * PRE_BLK;
+#pragma unroll
+    for (int r = 0; r < 32; r++) a[r] = pb[r];
+    transpose32(a);
+    const bool endA = c < CH;
+    const unsigned flip = endA ? ~0u : 0u;
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const int t = pack_t(q), pl = pack_pl(q);
+        const int dB = 2 * t + pl, dA = 2 * (15 - t) + pl;
+        pb[endA ? dA : dB] = pl ? (a[q] ^ flip) : a[q];
+    }
+}
+
+// Occurrence words of one text column -> this lane's scratch column (sc points at [buffer][symbol 0][lane]).
+// NX = extra symbol rows compiled in (0, or PRE_MAXSYM - 4 for panels with degenerate primer letters: unions of the four
+// base words under wave-uniform masks; a run-time loop here would put control flow into every unrolled DP column).
+template <int NX>
+SMX_HD void prescan_write_occ(unsigned *sc, unsigned b0, unsigned b1, const unsigned (&xm)[NX > 0 ? NX : 1][4]) {
+    const unsigned E0 = ~b0 & ~b1, E1 = b0 & ~b1, E2 = ~b0 & b1, E3 = b0 & b1;   // A, C, T, G
+    sc[0] = E0; sc[64] = E1; sc[128] = E2; sc[192] = E3;
+#pragma unroll
+    for (int x = 0; x < NX; x++)
+        sc[(4 + x) * 64] = (E0 & xm[x][0]) | (E1 & xm[x][1]) | (E2 & xm[x][2]) | (E3 & xm[x][3]);
+}
+
+// Phase 3: one lane = primer p against end X of group g's 32 reads.  `scratch` = this wave's PRE_SCRATCH dwords.
+// MR = rows compiled in; a pattern of m <= MR rows occupies rows MR - m .. MR - 1.  The rows above it are inert: they
+// read the all-ones word of scratch row PRE_MAXSYM and start with a zero vertical delta, so every delta on them stays 0 and
+// the first pattern row sees the free top row of the HW alignment (straight-line code, no per-row branch; jumping into
+// the unrolled rows instead cost hundreds of register copies per column).
+template <int MR, int NX>
+SMX_HD void prescan_dp(const unsigned *planes, unsigned *scratch, int lane, int g, int X, int CH, int ppr,
+                       const PreDesc &D, int p, PreRec (&out)[32]) {
+    const int m = D.m[p], skip = MR - m, nsym = D.nsym;
+    unsigned Pv[MR], Mv[MR];
+    int aoff[MR];
+#pragma unroll
+    for (int i = 0; i < MR; i++) {
+        Pv[i] = i >= skip ? ~0u : 0u; Mv[i] = 0u;
+        aoff[i] = (i >= skip ? (int)D.sym[p][i - skip] : PRE_MAXSYM) * 64 + lane;
+    }
+    unsigned st[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) st[r] = 0u;
+    unsigned xm[NX > 0 ? NX : 1][4];   // uniform: all-ones where extra symbol 4 + x contains A / C / T / G
+#pragma unroll
+    for (int x = 0; x < (NX > 0 ? NX : 1); x++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) xm[x][b] = (4 + x < nsym && ((D.symmask[4 + x] >> b) & 1)) ? ~0u : 0u;
+    unsigned g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, zero = ~0u;   // gap = score - running minimum, starts at 0
+    constexpr int bufw = PRE_SCRATCH / 2;   // compile-time buffer stride: the second buffer is an immediate offset
+    unsigned *sc0 = scratch + lane, *sc1 = scratch + bufw + lane;
+    sc0[PRE_MAXSYM * 64] = ~0u; sc1[PRE_MAXSYM * 64] = ~0u;   // the inert rows' Eq word (a row no symbol uses)
+    {   // prologue: column 0 of chunk 0
+        const unsigned *pb = planes + (g * ppr + (X ? CH : CH - 1)) * PRE_BLK;
+        prescan_write_occ<NX>(sc0, pb[0], pb[1], xm);
+    }
+    unsigned eqb[2][8];   // Eq words of the current / next row group
+#pragma unroll
+    for (int u = 0; u < 8; u++) eqb[0][u] = scratch[aoff[u]];   // column 0, group 0 (16 * NG columns per chunk: even parity)
+    for (int ch = 0; ch < CH; ch++) {
+        const unsigned *pb = planes + (g * ppr + (X ? CH + ch : CH - 1 - ch)) * PRE_BLK;
+        const unsigned *pbn = planes + (g * ppr + (X ? CH + ch + 1 : CH - 2 - ch)) * PRE_BLK;   // next chunk (unused after the last)
+        unsigned fl[32];   // [0,16): lt flags, [16,32): e flags of this chunk's columns
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            // next column's occurrence words go to the other scratch buffer while this column's are read
+            if (t < 15) prescan_write_occ<NX>((t & 1) ? sc0 : sc1, pb[2 * t + 2], pb[2 * t + 3], xm);
+            else if (ch + 1 < CH) prescan_write_occ<NX>(sc0, pbn[0], pbn[1], xm);
+            const unsigned *sc = ((t & 1) ? scratch + bufw : scratch);
+            unsigned Ph = 0u, Mh = 0u;   // HW: the top row is free
+            // rows in groups of eight.  The Eq words of the NEXT group (of the next column after the last group: its
+            // occurrence words were written one column ahead) are requested before this group's cells run, so one
+            // counted wait per group covers its eight reads; the scheduling fences pin that order.
+            constexpr int NG = (MR + 7) / 8;
+#pragma unroll
+            for (int gi = 0; gi < NG; gi++) {
+                const int cur = (t * NG + gi) & 1;
+                const int gn = gi + 1 < NG ? gi + 1 : 0;                        // next group ...
+                const unsigned *scn = gi + 1 < NG ? sc : ((t & 1) ? scratch : scratch + bufw);   // ... and its buffer
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (gn * 8 + u < MR) eqb[cur ^ 1][u] = scn[aoff[gn * 8 + u]];
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (gi * 8 + u < MR) {
+                    const int i = gi * 8 + u;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    // the cell as exactly five instructions, in this order: left to itself the compiler interleaves the
+                    // cells of several columns (more instructions per cell and hundreds of spilled registers).
+                    // v_bitop3 truth table index = s0 << 2 | s1 << 1 | s2: 0xfe = a | b | c, 0xf1 = a | ~(b | c)
+                    unsigned Z, nPh, nMh;
+                    asm volatile("v_bitop3_b32 %[z], %[eq], %[mh], %[mv] bitop3:0xfe\n\t"
+                                 "v_bitop3_b32 %[pho], %[mv], %[z], %[pv] bitop3:0xf1\n\t"
+                                 "v_and_b32 %[mho], %[pv], %[z]\n\t"
+                                 "v_bitop3_b32 %[pv], %[mh], %[z], %[ph] bitop3:0xf1\n\t"
+                                 "v_and_b32 %[mv], %[ph], %[z]"
+                                 : [z] "=&v"(Z), [pho] "=&v"(nPh), [mho] "=&v"(nMh), [pv] "+v"(Pv[i]), [mv] "+v"(Mv[i])
+                                 : [eq] "v"(eqb[cur][u]), [mh] "v"(Mh), [ph] "v"(Ph));
+                    Ph = nPh; Mh = nMh;
+#else
+                    const unsigned Z = eqb[cur][u] | Mh | Mv[i];
+                    const unsigned nPh = Mv[i] | ~(Z | Pv[i]);
+                    const unsigned nMh = Pv[i] & Z;
+                    const unsigned nPv = Mh | ~(Z | Ph);
+                    const unsigned nMv = Ph & Z;
+                    Pv[i] = nPv; Mv[i] = nMv; Ph = nPh; Mh = nMh;
+#endif
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            // last row: score += Ph - Mh; gap = score - running minimum
+            const unsigned lt = zero & Mh;        // at the minimum and going down: a new minimum, the gap stays 0
+            unsigned cy = Ph, bw = Mh ^ lt, tt;
+            tt = g0 & cy; g0 ^= cy; cy = tt;
+            tt = g1 & cy; g1 ^= cy; cy = tt;
+            tt = g2 & cy; g2 ^= cy; cy = tt;
+            tt = g3 & cy; g3 ^= cy; cy = tt;
+            g4 ^= cy;
+            tt = ~g0 & bw; g0 ^= bw; bw = tt;
+            tt = ~g1 & bw; g1 ^= bw; bw = tt;
+            tt = ~g2 & bw; g2 ^= bw; bw = tt;
+            tt = ~g3 & bw; g3 ^= bw; bw = tt;
+            g4 ^= bw;
+            zero = ~(g0 | g1 | g2 | g3 | g4);
+            fl[t] = lt;
+            fl[16 + t] = zero;
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);   // keep the live ranges column-sized: no hoisting of later columns' LDS reads
+#endif
+        }
+        transpose32(fl);
+#pragma unroll
+        for (int r = 0; r < 32; r++) fold16(fl[r], ch, st[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 32; r++) out[r] = make_rec(st[r], m, (int)D.k[p]);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Host: PreDesc from the searched patterns.  eq(pattern letter, text base) is the panel's equality relation.  Returns
+// false when the prescan cannot serve this panel (the demux kernel then scans every alignment itself).
+inline bool prescan_build_desc(PreDesc *D, int NP, int S, const char *const *patterns, const int *lens, const int *ks,
+                               bool (*eq)(unsigned char, unsigned char)) {
+    if (NP < 1 || NP > 64 || S < 16 || S > 256 || (S & 15) != 0) return false;
+    D->NP = NP; D->S = S;
+    static const char bases[4] = {'A', 'C', 'T', 'G'};   // 2-bit text code order
+    D->nsym = 4;
+    for (int s = 0; s < 4; s++) D->symmask[s] = (uint8_t)(1u << s);
+    for (int p = 0; p < NP; p++) {
+        if (lens[p] < 1 || lens[p] > PRE_MAXROWS || ks[p] < 0 || ks[p] >= lens[p]) return false;
+        D->m[p] = (uint8_t)lens[p];
+        D->k[p] = (uint8_t)ks[p];
+        for (int i = 0; i < lens[p]; i++) {
+            unsigned mk = 0;
+            for (int b = 0; b < 4; b++) if (eq((unsigned char)patterns[p][i], (unsigned char)bases[b])) mk |= 1u << b;
+            int s = 0;
+            while (s < D->nsym && D->symmask[s] != mk) s++;
+            if (s == D->nsym) {
+                if (D->nsym == PRE_MAXSYM) return false;
+                D->symmask[D->nsym++] = (uint8_t)mk;
+            }
+            D->sym[p][i] = (uint8_t)s;
+        }
+    }
+    D->pure4 = D->nsym == 4;
+    return true;
+}
+
+}  // namespace smx
+#endif

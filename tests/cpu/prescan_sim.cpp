@@ -1,0 +1,147 @@
+// CPU simulation of the primer prescan (specimux_amd/csrc/smx_prescan_core.h): the same host/device functions the
+// gfx950 kernel runs, with lanes as loop indices and LDS as an array, checked against a plain O(mn) DP per
+// (read, primer, end).  Built and run by tests/test_prescan_cpu.py (g++, no GPU).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "smx_prescan_core.h"
+
+using namespace smx;
+
+static bool eq_iupac(unsigned char p, unsigned char t) {
+    static const char *pairs[] = {"YC", "YT", "RA", "RG", "NA", "NC", "NG", "NT", "WA", "WT", "MA", "MC", "SC", "SG",
+                                  "KG", "KT", "BC", "BG", "BT", "DA", "DG", "DT", "HA", "HC", "HT", "VA", "VC", "VG"};
+    if (p == t) return true;
+    for (const char *q : pairs)
+        if ((q[0] == p && q[1] == t) || (q[1] == p && q[0] == t)) return true;
+    return false;
+}
+
+static char comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; }
+
+// scalar reference: HW alignment, all columns; best, jstar (first column at the final minimum), optimal-end set
+static PreRec reference(const std::string &pat, int k, const std::string &text) {
+    const int m = (int)pat.size(), n = (int)text.size();
+    std::vector<int> col(m + 1), score(n);
+    for (int i = 0; i <= m; i++) col[i] = i;
+    for (int j = 0; j < n; j++) {
+        int diag = col[0];
+        col[0] = 0;
+        for (int i = 1; i <= m; i++) {
+            int v = std::min(std::min(col[i] + 1, col[i - 1] + 1), diag + (eq_iupac((unsigned char)pat[i - 1], (unsigned char)text[j]) ? 0 : 1));
+            diag = col[i];
+            col[i] = v;
+        }
+        score[j] = col[m];
+    }
+    int best = m;   // the prescan's running minimum starts at m (never a match: k < m)
+    int jstar = 0;
+    for (int j = 0; j < n; j++) if (score[j] < best) { best = score[j]; jstar = j; }
+    PreRec r;
+    if (best > k) { r.meta = 0xFF; r.relmask = 0; return r; }
+    unsigned mask = 0, ovf = 0;
+    for (int j = jstar; j < n; j++)
+        if (score[j] == best) { if (j - jstar < PRE_RELBITS) mask |= 1u << (j - jstar); else ovf = 1; }
+    r.meta = (unsigned)best | ((unsigned)jstar << 8) | (ovf << 31);
+    r.relmask = mask;
+    return r;
+}
+
+int main(int argc, char **argv) {
+    const int S = argc > 1 ? atoi(argv[1]) : 80;
+    const unsigned seed = argc > 2 ? (unsigned)atoi(argv[2]) : 1;
+    const int CH = S / 16, ppr = 2 * CH;
+    std::mt19937 rng(seed);
+    // patterns = primer reverse complements as the kernel searches them; one degenerate, one short, one 31-mer
+    std::vector<std::string> pats = {"TTACTTCCTCTAAATGACCAAG", "GCATATCAATAAGCGGAGGA", "GTGARTCATCGAATCTTTG", "ACGTNACGTYACGKA",
+                                     "ACGTTGCATGCCATGACTGACTAGCTAGCAT"};
+    std::vector<int> lens, ks = {7, 6, 5, 3, 9};
+    if (argc > 3) { pats.erase(pats.begin() + 3); ks.erase(ks.begin() + 3); }   // one degenerate letter only: nsym = 5
+    std::vector<const char *> pp;
+    for (auto &s : pats) { lens.push_back((int)s.size()); pp.push_back(s.c_str()); }
+    const int NP = (int)pats.size();
+    PreDesc D;
+    memset(&D, 0, sizeof(D));
+    if (!prescan_build_desc(&D, NP, S, pp.data(), lens.data(), ks.data(), eq_iupac)) { printf("desc failed\n"); return 2; }
+    // a tile of reads: windows [read][2 * S] ASCII (head | tail)
+    const int n = PRE_TILE;
+    std::vector<unsigned char> win((size_t)n * 2 * S);
+    auto rnd_base = [&] { return "ACGT"[rng() & 3]; };
+    std::vector<std::string> heads(n), tails(n);
+    for (int r = 0; r < n; r++) {
+        std::string h(S, 'A'), t(S, 'A');
+        for (auto &c : h) c = rnd_base();
+        for (auto &c : t) c = rnd_base();
+        // plant mutated copies (in the orientation the scan sees them): end B sees the tail as is, end A revcomp(head)
+        for (int e = 0; e < 2; e++) {
+            if (rng() % 4 == 0) continue;
+            const std::string &pat = pats[rng() % NP];
+            std::string cp;
+            for (char c : pat) {   // instantiate degenerate letters, then mutate
+                char b = c;
+                if (!strchr("ACGT", c)) { do { b = rnd_base(); } while (!eq_iupac((unsigned char)c, (unsigned char)b)); }
+                unsigned u = rng() % 100;
+                if (u < 6) b = rnd_base();
+                else if (u < 9) continue;            // deletion
+                else if (u < 12) cp.push_back(rnd_base());   // insertion
+                cp.push_back(b);
+            }
+            std::string tgt = e ? t : h;
+            if ((int)cp.size() >= S) continue;
+            int pos = (int)(rng() % (S - cp.size() + 1));
+            if (rng() % 8 == 0) pos = S - (int)cp.size();   // flush with the window end
+            if (rng() % 8 == 0) pos = 0;
+            if (e) { tgt.replace(pos, cp.size(), cp); t = tgt; }
+            else {   // the scan sees revcomp(head): write revcomp(cp) into the head
+                std::string rc(cp.rbegin(), cp.rend());
+                for (auto &c : rc) c = comp(c);
+                tgt.replace(pos, cp.size(), rc);
+                h = tgt;
+            }
+        }
+        if (r % 97 == 0) { h.assign(S, 'A'); t.assign(S, 'T'); }   // low-complexity: many optimal ends (overflow path)
+        heads[r] = h; tails[r] = t;
+        memcpy(&win[(size_t)r * 2 * S], h.data(), S);
+        memcpy(&win[(size_t)r * 2 * S + S], t.data(), S);
+    }
+    // ---- the kernel's phases on the host
+    std::vector<unsigned> planes((size_t)PRE_G * ppr * PRE_BLK + 64, 0u);
+    for (int q = 0; q < n * ppr; q++) {   // phase 1
+        const int read = q / ppr, c = q % ppr;
+        unsigned w[4];
+        memcpy(w, &win[(size_t)read * 2 * S + 16 * c], 16);
+        prescan_store_piece(planes.data(), read, c, ppr, w[0], w[1], w[2], w[3]);
+    }
+    for (int b = 0; b < PRE_G * ppr; b++) prescan_transpose_block(planes.data(), b, b % ppr, CH);   // phase 2
+    std::vector<unsigned> scratch(PRE_SCRATCH);
+    long bad = 0, checked = 0, matched = 0, ovf = 0;
+    for (int p = 0; p < NP; p++)
+        for (int lane = 0; lane < 64; lane++) {   // phase 3: lane = (group, end)
+            const int g = lane >> 1, X = lane & 1;
+            PreRec out[32];
+            if (D.m[p] <= 24) prescan_dp<24, PRE_MAXSYM - 4>(planes.data(), scratch.data(), lane, g, X, CH, ppr, D, p, out);
+            else prescan_dp<31, PRE_MAXSYM - 4>(planes.data(), scratch.data(), lane, g, X, CH, ppr, D, p, out);
+            for (int r = 0; r < 32; r++) {
+                const int read = g * 32 + r;
+                std::string text;
+                if (X) text = tails[read];
+                else { text.assign(heads[read].rbegin(), heads[read].rend()); for (auto &c : text) c = comp(c); }
+                const PreRec exp = reference(pats[p], ks[p], text);
+                checked++;
+                if ((exp.meta & 0xFF) != 0xFF) matched++;
+                if (exp.meta >> 31) ovf++;
+                if (exp.meta != out[r].meta || exp.relmask != out[r].relmask) {
+                    if (bad < 10)
+                        printf("MISMATCH read %d primer %d end %d: got %08x %08x expected %08x %08x\n", read, p, X, out[r].meta,
+                               out[r].relmask, exp.meta, exp.relmask);
+                    bad++;
+                }
+            }
+        }
+    printf("S=%d seed=%u: %ld alignments checked, %ld matched, %ld overflow, %ld mismatches\n", S, seed, checked, matched, ovf, bad);
+    return bad ? 1 : 0;
+}

@@ -141,7 +141,7 @@ struct smx_panel {
     smx::PreDesc pre;
     int pre_nw = 2, pre_mr = 24, pre_nx = 0, pre_blocks_per_cu = 1;
     size_t pre_lds = 0;
-    DevBuf pre_recs[SMX_MAX_STREAMS];        // per stream slot: [2 * NP][n_reads rounded up to a tile] PreRec
+    DevBuf pre_recs[SMX_MAX_STREAMS];        // per stream slot: [2 * NP][search_len / 16][n_reads rounded up to a tile] flag words
     unsigned long long *d_phase = nullptr;   // SMX_PHASE_TIMING diagnostic
     int phase_grid = 0;
 };
@@ -525,11 +525,11 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         tc = P->d_tile_counter + 16 * slot;
     }
     // primer prescan in front of the demux kernel (same stream: ordered)
-    const smx::PreRec *d_pre = nullptr;
+    const unsigned *d_pre = nullptr;
     uint32_t npad = 0;
     if (P->pre_ok) {
         npad = (n_reads + smx::PRE_TILE - 1) / smx::PRE_TILE * smx::PRE_TILE;
-        const size_t need = (size_t)2 * P->hp.NP * npad * sizeof(smx::PreRec);
+        const size_t need = (size_t)2 * P->hp.NP * (P->hp.S >> 4) * npad * sizeof(unsigned);
         DevBuf &pb = P->pre_recs[slot];
         if (need > pb.cap) {
             if (pb.p) (void)hipStreamSynchronize((hipStream_t)stream);   // earlier launches on this stream still read it
@@ -538,10 +538,10 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         }
         const uint32_t ptiles = npad / smx::PRE_TILE;
         const int pgrid = (int)std::min<uint32_t>(ptiles, (uint32_t)(P->n_cu * P->pre_blocks_per_cu));
-        int pe = smx_launch_prescan(&P->pre, P->pre_nw, P->pre_mr, P->pre_nx, pgrid, P->pre_lds, stream, d_windows, n_reads,
-                                    P->hp.wstride, (smx::PreRec *)pb.p, npad);
+        int pe = smx_launch_prescan(&P->pre, P->pre_nw, P->pre_mr, P->pre_nx, pgrid, P->pre_lds, stream, d_windows, d_lens,
+                                    n_reads, P->hp.wstride, (unsigned *)pb.p, npad);
         if (pe != 0) return fail(SMX_ERR_DEVICE, "prescan kernel launch failed: %s", hipGetErrorString((hipError_t)pe));
-        d_pre = (const smx::PreRec *)pb.p;
+        d_pre = (const unsigned *)pb.p;
     }
     uint32_t tiles = (n_reads + R - 1) / R;
     int grid = (int)std::min<uint32_t>(tiles, (uint32_t)(P->n_cu * (use_slots ? P->blocks_per_cu_slots : P->blocks_per_cu)));

@@ -178,7 +178,7 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.namask = o; o += R * 2 * MW * 4;         // per code row: bit j set = code[j] is not A/C/G/T
     t.lens = o;  o += 2 * R * 4;               // double-buffered: the next tile is encoded while this one is scored
     t.ocnt = o;  o += 2 * R * 4;               // per read: forward votes | reverse votes << 16; double-buffered
-    t.rflag = o; o += 2 * R * 4;               // per read: 1 = the prescan cannot speak for it (short / non-ACGT window); double-buffered
+    t.rflag = o; o += 2 * R * 4;               // per read: 1 = a window holds something other than upper-case ACGT: scalar primer scan; double-buffered
     t.hits = o;  o += R * H * (int)sizeof(HitL);
     t.tiem = o;  o += R * H * t.MBW * 4;
     // time-shared regions: {location entries} are dead after the barcode scan -> staged result records;
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                                                     uint32_t extra_cap, uint32_t *n_extra,
                                                     unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist,
                                                     unsigned *tile_counter, int use_slots,
-                                                    const PreRec *__restrict__ pre, uint32_t npad) {
+                                                    const unsigned *__restrict__ pre, uint32_t npad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
     const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
@@ -1062,8 +1062,12 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         const int *rflagC = rflag + par * R;
         if (timing) tacc[10] = clock64();
         if (have) {
-        // ---- phase 2: primer scan, one lane per (read, primer, end)
-        for (int item = tid; item < nh; item += NT) {
+        // ---- phase 2: primer scan, one lane per (read, primer, end).  With the prescan (pre != nullptr) every alignment
+        // it covers is decoded from its flag words; the others (windows with anything but upper-case ACGT) are queued
+        // and scanned afterwards, packed into the lowest lanes, so that one such read does not make its whole wave run
+        // the 80-column scalar scan.
+        unsigned short *fbq = queue;   // fallback items (the rank -> hit queue is not live before phase 3a)
+        auto primer_item = [&](int item, const bool use_pre) {
             int r = divH(item), h = item - __mul24(r, H), p = h >> 1, X = h & 1;
             int L = lensC[r];
             EndGeom g = end_geom(L, S);
@@ -1076,23 +1080,20 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 #if defined(SMX_EXP) && SMX_EXP == 7
             g.Sp = 0; g.j_lo = 1;   // timing experiment: no primer columns
 #endif
-            // the prescan kernel has aligned this primer over this window already (bit-sliced over 32 reads,
-            // smx_prescan_core.h) unless the read is short or holds anything but upper-case ACGT, or the optimal ends
-            // spread too far for its record: those alignments are (re)done by the scalar scan below
-            bool pre_done = false;
-            if (pre != nullptr && rflagC[r] == 0) {
-                const uint2 rec = ((const uint2 *)pre)[(size_t)h * npad + r0 + (uint32_t)r];
-                if (!(rec.x >> 31)) {
-                    pre_done = true;
-                    const int pb = (int)(rec.x & 0xFFu);
-                    unsigned long long bits = 0;
-                    if (pb != 0xFF) {
-                        best = pb; jstar = (int)((rec.x >> 8) & 0xFFu); cnt = __popc(rec.y);
-                        bits = (unsigned long long)rec.y << (jstar & 31);
-                    }
-                    for (int w = 0; w < MW; w++)
-                        mrow[w] = w == (jstar >> 5) ? (unsigned)bits : (w == (jstar >> 5) + 1 ? (unsigned)(bits >> 32) : 0u);
-                }
+#if defined(SMX_EXP) && SMX_EXP == 8
+            if (!use_pre) { g.Sp = 0; g.j_lo = 1; }   // timing experiment: the fallback pass scans no columns (short reads never match)
+#endif
+            // With the prescan: its flag words cover the window's first Sp columns = the whole stored window, which is the
+            // primer target unless the read is shorter than search_len AND its target starts inside the window
+            // (g.j_lo > 0): then only the orientation vote comes from the prescan (determine_orientation looks
+            // at the whole string) and the target [j_lo, Sp) -- at most search_len / 2 columns -- is scanned below.
+            bool pre_done = false, pre_omatch = false;
+            if (use_pre) {
+                const int bfull = prescan_decode(pre + (size_t)h * (S >> 4) * npad + r0 + (uint32_t)r, npad, S >> 4, MW, m, k, g.Sp,
+                                                 mrow, &jstar, &cnt);
+                pre_omatch = bfull <= k;
+                if (g.j_lo == 0) { pre_done = true; best = pre_omatch ? bfull : m + 1; }
+                else { jstar = 0; cnt = 0; }
             }
             if (pre_done) {
             } else if (sizeof(PW) == 4 && g.j_lo == 0 && g.Sp == S && (S & 3) == 0) {
@@ -1156,22 +1157,17 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     cnt += __popc(word);
                 }
             } else {
-                for (int w = 0; w < MW; w++) {
-                    unsigned word = 0;
-                    int jend = (w + 1) * 32 < S ? (w + 1) * 32 : S;
-                    for (int j = w * 32; j < jend; j++) {
-                        if (j >= g.j_lo && j < g.Sp) {
-                            myers_step<PW, false>(peq[(int)cw[j] << lNPs], Pvv, Mv, score, top);
-                            if (score < best) { best = score; jstar = j; cnt = 0; }
-                            if (score == best) { cnt++; word |= 1u << (j & 31); }
-                        }
-                    }
-                    mrow[w] = word;
+                for (int w = 0; w < MW; w++) mrow[w] = 0;
+                for (int j = g.j_lo; j < g.Sp; j++) {
+                    myers_step<PW, false>(peq[(int)cw[j] << lNPs], Pvv, Mv, score, top);
+                    if (score < best) { best = score; jstar = j; cnt = 0; }
+                    if (score == best) { cnt++; mrow[j >> 5] |= 1u << (j & 31); }   // bits before jstar are stale: ignored
                 }
             }
             bool matched = best <= k;
             bool omatch = matched;
-            if (g.j_lo > 0) {   // short read: determine_orientation looks at the whole string (Q1)
+            if (g.j_lo > 0 && use_pre) omatch = pre_omatch;
+            else if (g.j_lo > 0) {   // short read: determine_orientation looks at the whole string (Q1)
                 PW P2 = ~(PW)0, M2 = 0;
                 int sc = m, b2 = m + 1;
                 for (int j = 0; j < g.Sp; j++) {
@@ -1210,8 +1206,21 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 int vote_fwd = (dir == 0) ? (X == 0) : (X == 1);
                 atomicAdd(&ocntC[r], vote_fwd ? 1 : 0x10000);
             }
+        };
+        if (pre != nullptr) {
+            for (int item = tid; item < nh; item += NT) {
+                if (rflagC[divH(item)] == 0) primer_item(item, true);
+                else fbq[atomicAdd(&aggr[10], 1)] = (unsigned short)item;
+            }
+            __syncthreads();
+            const int nfb = aggr[10];
+            for (int i = tid; i < nfb; i += NT) primer_item((int)fbq[i], false);
+            __syncthreads();
+            if (tid == 0) aggr[10] = 0;   // read by everyone before the barrier above; next written in the next tile's phase 2
+        } else {
+            for (int item = tid; item < nh; item += NT) primer_item(item, false);
+            __syncthreads();
         }
-        __syncthreads();
         STAMP(1);
 
         // ---- phase 3a: orientation, which ends need barcodes; block-wide scans of locations and searched hits;
@@ -1680,14 +1689,14 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                             unsigned cd = lut[256 + ch];
                             int j = Sp - 1 - pos;
                             rowA[j] = (unsigned char)cd;
-                            if (cd > 3) atomicOr(&namask[(r * 2 + 0) * MW + (j >> 5)], 1u << (j & 31));
+                            if (cd > 3) { atomicOr(&namask[(r * 2 + 0) * MW + (j >> 5)], 1u << (j & 31)); rflag[(par ^ 1) * R + r] = 1; }
                         }
                     } else if (pos < 2 * S) { // tail byte j -> B[j]
                         int j = pos - S;
                         if (j < Sp) {
                             unsigned cd = lut[ch];
                             rowB[j] = (unsigned char)cd;
-                            if (cd > 3) atomicOr(&namask[(r * 2 + 1) * MW + (j >> 5)], 1u << (j & 31));
+                            if (cd > 3) { atomicOr(&namask[(r * 2 + 1) * MW + (j >> 5)], 1u << (j & 31)); rflag[(par ^ 1) * R + r] = 1; }
                         }
                     }
                 }
@@ -1721,7 +1730,6 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 #pragma unroll
                         for (int q = 0; q < 4; q++) dst[tail ? 4 * c + q : S4 - 1 - (4 * c + q)] = pk[q];
                     } else {
-                        rflag[(par ^ 1) * R + r] = 1;   // short read or a non-ACGT byte: the scalar primer scan takes this read
                         encode_bytes(r, L, (tail ? S : 0) + 16 * c, v);
                     }
                 }
@@ -1829,7 +1837,7 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
                                 const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops,
                                 smx_op *d_extra, uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts,
                                 smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter, int use_slots,
-                                const smx::PreRec *d_pre, uint32_t npad) {
+                                const unsigned *d_pre, uint32_t npad) {
     hipStream_t s = (hipStream_t)stream;
     // d_tile_counter = {tile queue head, -, finished workgroups, extra records}: zero at allocation, re-armed by
     // the last workgroup of every launch

@@ -5,8 +5,9 @@
 // for the current / next column's base-occurrence words.  Three workgroups of two waves share a CU at S = 80.
 // Wave w aligns primers w, w + NW, ... (the pattern letters are wave-uniform: kernel-argument loads); its 64 lanes are
 // the tile's 32 groups x 2 ends.  A lane keeps the DP column (2 x rows), the rows' scratch addresses, the 5-plane gap
-// counter, 32 flag words of the current 16-column chunk and the 2 x 32 words of per-read fold state in registers:
-// ~200 VGPRs, two waves per SIMD.  Output: one 8-byte PreRec per (primer, end, read), layout [primer * 2 + end][read].
+// counter and the 32 flag words of the current 16-column chunk in registers:
+// ~200 VGPRs, two waves per SIMD.  Output: one flag word per (primer, end, 16-column chunk, read), layout
+// [primer * 2 + end][chunk][read] (prescan_decode turns the chunk words of one alignment into distance / ends).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -17,7 +18,7 @@ namespace smx {
 template <int NW, int MR, int NX>   // NX = extra (degenerate-letter) symbol rows; MR = DP rows compiled in: 24 when every primer has <= 24 nt, else 31 (one variant per kernel:
                            // two DP bodies in one kernel made the register allocator spill hundreds of registers)
 __global__ __launch_bounds__(NW * 64, 2) void prescan_kernel(PreDesc D, const uint8_t *__restrict__ windows,
-                                                             uint32_t n_reads, int stride, PreRec *__restrict__ out,
+                                                             const int32_t *__restrict__ lens, uint32_t n_reads, int stride, unsigned *__restrict__ out,
                                                              uint32_t npad, uint32_t ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned plds[];
     constexpr int NT = NW * 64;
@@ -37,7 +38,17 @@ __global__ __launch_bounds__(NW * 64, 2) void prescan_kernel(PreDesc D, const ui
 #pragma unroll 8
             for (int q = tid; q < npieces; q += NT) {
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (r0 + (uint32_t)read < n_reads) v = src[q];
+                if (r0 + (uint32_t)read < n_reads) {
+                    v = src[q];
+                    if (c < CH) {   // head window of a short read (rare): right-aligned, see prescan_short_head_piece
+                        const int L = lens[r0 + (uint32_t)read];
+                        if (L < D.S) {
+                            unsigned w4[4];
+                            prescan_short_head_piece(windows + (size_t)(r0 + (uint32_t)read) * stride, c, D.S, L, w4);
+                            v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                        }
+                    }
+                }
                 prescan_store_piece(planes, read, c, ppr, v.x, v.y, v.z, v.w);
                 read += dr; c += dc;
                 if (c >= ppr) { c -= ppr; read++; }
@@ -53,12 +64,8 @@ __global__ __launch_bounds__(NW * 64, 2) void prescan_kernel(PreDesc D, const ui
         // ---- phase 3 + 4: this wave's primers
         const int g = lane >> 1, X = lane & 1;
         for (int p = wave; p < D.NP; p += NW) {
-            PreRec rec[32];
-            prescan_dp<MR, NX>(planes, scratch, lane, g, X, CH, ppr, D, p, rec);
-            uint4 *dst = (uint4 *)(out + (size_t)(2 * p + X) * npad + r0 + (uint32_t)g * 32u);
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                dst[i] = make_uint4(rec[2 * i].meta, rec[2 * i].relmask, rec[2 * i + 1].meta, rec[2 * i + 1].relmask);
+            prescan_dp<MR, NX>(planes, scratch, lane, g, X, CH, ppr, D, p,
+                               out + (size_t)(2 * p + X) * CH * npad + r0 + (uint32_t)g * 32u, npad);
         }
         __syncthreads();   // the next tile's phase 1 rewrites the planes
     }
@@ -84,8 +91,8 @@ static const void *prescan_fn(int nw, int mr, int nx) {
 // nw = 2 or 4 waves per workgroup, mr = longest primer of the panel, nx = number of degenerate-letter symbols;
 // grid = resident workgroups (the caller sizes it)
 extern "C" int smx_launch_prescan(const smx::PreDesc *D, int nw, int mr, int nx, int grid, size_t lds_bytes, void *stream,
-                                  const uint8_t *d_windows, uint32_t n_reads, int stride, smx::PreRec *d_out,
-                                  uint32_t npad) {
+                                  const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride,
+                                  unsigned *d_out, uint32_t npad) {
     static_assert(smx::PRE_MAXROWS == 31 && smx::PRE_MAXSYM == 8, "variant table");
     const uint32_t ntiles = (n_reads + smx::PRE_TILE - 1) / smx::PRE_TILE;
     hipStream_t s = (hipStream_t)stream;
@@ -93,7 +100,7 @@ extern "C" int smx_launch_prescan(const smx::PreDesc *D, int nw, int mr, int nx,
 #define X(NWV, MRV, NXV)                                                                                                  \
     if (nwv == NWV && mrv == MRV && nxv == NXV)                                                                           \
         hipLaunchKernelGGL((smx::prescan_kernel<NWV, MRV, NXV>), dim3(grid), dim3(NWV * 64), lds_bytes, s, *D, d_windows, \
-                           n_reads, stride, d_out, npad, ntiles);
+                           d_lens, n_reads, stride, d_out, npad, ntiles);
     SMX_PRE_VARIANTS(X)
 #undef X
     return (int)hipGetLastError();

@@ -3,9 +3,12 @@
 // (bit r of every word belongs to read r of the lane's 32-read group).  Replaces the per-(read, primer, end) bit-vector
 // scan of the demux kernel for the common case -- full-length windows of upper-case A/C/G/T -- at ~1/4 of its VALU
 // work: 5 three-input bit-ops per DP cell serve 32 reads, against ~22 instructions per text column per read.
-// Reads the scan cannot take (shorter than search_len, any other character in a window) and alignments whose optimal
-// ends spread over more than 16 columns are redone by the demux kernel's scalar scan; its results are bit-identical
-// (reference: match_one_end demultiplex.py:755-770, align_seq alignment.py:21-50, edlib HW mode).
+// Reads with any other character in a window are redone by the demux kernel's scalar scan; the results are
+// bit-identical (reference: match_one_end demultiplex.py:755-770, align_seq alignment.py:21-50, edlib HW mode).
+// Reads shorter than search_len are covered too: the DP is causal (column j depends on columns <= j only), so the flags
+// of the first n columns are those of the n-column text; the head window of a short read is right-aligned while it is
+// packed, which makes revcomp(head) start at column 0 like the scalar scan's window A, and the consumer decodes the
+// first min(len, search_len) columns only.
 //
 // This header is host/device code: the kernel (smx_prescan.hip) and the CPU unit test (tests/cpu/prescan_sim.cpp) run
 // the same functions; on the host a "lane" is a loop index and LDS is a plain array.
@@ -21,10 +24,11 @@
 //            Unit-cost cell on the vertical / horizontal deltas (5 bit-ops), HW boundaries (top row free).
 //            Last-row bookkeeping: gap = score - running minimum as a 5-plane bit-sliced counter;
 //            lt = "new minimum here", e = "at the minimum here" -- two flag words per column.
-//            Every 16 columns the 16 lt + 16 e words are transposed back (one 32 x 32 transpose) and folded into the
-//            per-read state: number of minima so far (best = m - count), column of the last one (= first column at the
-//            final minimum: jstar), and the e flags of the 16 columns from jstar on (relmask).
-//   phase 4  one 8-byte record per (read, primer, end): best distance (or "no match within k"), jstar, relmask.
+//            Every 16 columns the 16 lt + 16 e words are transposed back (one 32 x 32 transpose): one word per read =
+//            lt flags (bits 0-15) | e flags (bits 16-31) of the chunk's columns, written to HBM as
+//            [primer * 2 + end][chunk][read].  The consumer (prescan_decode, run by the demux kernel per alignment)
+//            needs nothing else: best = m - popcount(lt), jstar = last lt column (= first column at the final minimum),
+//            optimal ends = e flags from jstar on.
 #ifndef SMX_PRESCAN_CORE_H
 #define SMX_PRESCAN_CORE_H
 #include <stdint.h>
@@ -43,10 +47,6 @@ constexpr int PRE_MAXROWS = 31;    // primers up to 31 nt (5-plane gap counter)
 constexpr int PRE_MAXSYM = 8;      // distinct pattern letters (as A/C/G/T sets) per panel
 constexpr int PRE_BLK = 33;        // dwords per 32 x 32 bit block in LDS (odd: conflict-free column access)
 constexpr int PRE_SCRATCH = 2 * (PRE_MAXSYM + 1) * 64;   // dwords of per-wave scratch: [2 buffers][symbol][lane]
-
-// Record layout: meta bits 0-7 = best distance (0xFF: no match within k), 8-15 = jstar, bit 31 = the optimal ends
-// spread beyond jstar + 15 (redo with the scalar scan); relmask bit i (< 16) = column jstar + i is an optimal end.
-struct PreRec { uint32_t meta, relmask; };
 
 // Host-built description of the patterns (device copy passed by value to the kernel).
 struct PreDesc {
@@ -84,36 +84,56 @@ SMX_HD unsigned pack16(unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
 SMX_HD int pack_t(int q) { return 4 * ((q & 7) >> 1) + (q >> 3); }
 SMX_HD int pack_pl(int q) { return q & 1; }
 
-// ---- per-read fold of one 16-column chunk: w = lt flags (bits 0-15) | e flags (bits 16-31), column 16 * ch + t at bit t.
-// One state word per read (the fold state of a lane's 32 reads lives in registers): bits 0-15 relmask, 16-20 number of
-// minima so far, 21-28 column of the last one, bit 31 overflow (an optimal end at or beyond jstar + PRE_RELBITS).
-constexpr int PRE_RELBITS = 16;
-SMX_HD void fold16(unsigned w, int ch, unsigned &st) {
-    const unsigned lt16 = w & 0xFFFFu, e16 = w >> 16;
-    const int col0 = 16 * ch;
-    if (lt16) {
+// ---- consumer side: one alignment from its CH chunk words (w[c * cstride], c = 0 .. CH-1).  Returns the best distance
+// (> k: no match) and, for a match, jstar, the number of optimal ends and the S-bit mask of optimal end columns
+// (mrow: MW = ceil(S / 32) words, bits below jstar cleared).
+// Only the first n_valid columns count (reads shorter than the window).
+SMX_HD int prescan_decode(const unsigned *w, size_t cstride, int CH, int MW, int m, int k, int n_valid, unsigned *mrow,
+                          int *jstar_out, int *nloc_out) {
+    unsigned short *mrow16 = (unsigned short *)mrow;
+    int nlt = 0, jstar = 0;
+    for (int c0 = 0; c0 < CH; c0 += 8) {
+        unsigned xs[8];   // all loads of a batch are issued before the first is used: one memory round trip, not eight
+#pragma unroll
+        for (int u = 0; u < 8; u++) xs[u] = c0 + u < CH ? w[(size_t)(c0 + u) * cstride] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int c = c0 + u;
+            if (c < CH) {
+                const int nv = n_valid - 16 * c;   // valid columns of this chunk
+                const unsigned keep = nv >= 16 ? 0xFFFFu : (nv > 0 ? (1u << nv) - 1u : 0u);
+                const unsigned x = xs[u] & (keep | (keep << 16));
+                const unsigned lt16 = x & 0xFFFFu;
 #if defined(__HIP_DEVICE_COMPILE__)
-        const int last = 31 - __clz((int)lt16);
-        const int pc = __popc(lt16);
+                nlt += __popc(lt16);
+                if (lt16) jstar = 16 * c + 31 - __clz((int)lt16);
 #else
-        const int last = 31 - __builtin_clz(lt16);
-        const int pc = __builtin_popcount(lt16);
+                nlt += __builtin_popcount(lt16);
+                if (lt16) jstar = 16 * c + 31 - __builtin_clz(lt16);
 #endif
-        st = (e16 >> last) | ((((st >> 16) & 31u) + (unsigned)pc) << 16) | ((unsigned)(col0 + last) << 21);
-    } else {
-        int sh = col0 - (int)((st >> 21) & 0xFFu);
-        if (sh > 16) sh = 16;
-        const unsigned v = e16 << sh;   // bits that leave the 16-bit window mean "optimal end too far from jstar"
-        st |= (v & 0xFFFFu) | ((v >> 16) ? 0x80000000u : 0u);
+                mrow16[c] = (unsigned short)(x >> 16);
+            }
+        }
     }
-}
-
-SMX_HD PreRec make_rec(unsigned st, int m, int k) {
-    PreRec r;
-    const int best = m - (int)((st >> 16) & 31u);
-    if (best <= k) { r.meta = (unsigned)best | (((st >> 21) & 0xFFu) << 8) | (st & 0x80000000u); r.relmask = st & 0xFFFFu; }
-    else { r.meta = 0xFFu; r.relmask = 0; }
-    return r;
+    if (CH & 1) mrow16[CH] = 0;
+    const int best = m - nlt;
+    int nloc = 0;
+    if (best <= k) {
+        for (int i = 0; i < MW; i++) {
+            unsigned v = mrow[i];
+            if (i < (jstar >> 5)) v = 0;
+            else if (i == (jstar >> 5)) v &= ~0u << (jstar & 31);
+            mrow[i] = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+            nloc += __popc(v);
+#else
+            nloc += __builtin_popcount(v);
+#endif
+        }
+    }
+    *jstar_out = jstar;
+    *nloc_out = nloc;
+    return best;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -123,6 +143,17 @@ SMX_HD void prescan_store_piece(unsigned *planes, int read_in_tile, int c, int p
                                 unsigned w3) {
     const int g = read_in_tile >> 5, rr = read_in_tile & 31;
     planes[(g * ppr + c) * PRE_BLK + rr] = pack16(w0, w1, w2, w3);
+}
+
+// Head window piece c of a read shorter than S: the stored window holds head[0 : L) left-aligned; the prescan wants it
+// right-aligned (byte x of the S-byte head window <- head[x - (S - L)]) so that its reverse complement starts at column 0.
+SMX_HD void prescan_short_head_piece(const uint8_t *row, int c, int S, int L, unsigned (&w)[4]) {
+    const int sh = S - (L < 0 ? 0 : L);
+    w[0] = w[1] = w[2] = w[3] = 0u;
+    for (int i = 0; i < 16; i++) {
+        const int x = 16 * c + i - sh;
+        if (x >= 0) w[i >> 2] |= (unsigned)row[x] << (8 * (i & 3));
+    }
 }
 
 // Phase 2, one block: transpose in place into DP order.  Pieces c < CH are the head window (end A: stored reversed and
@@ -162,8 +193,9 @@ SMX_HD void prescan_write_occ(unsigned *sc, unsigned b0, unsigned b1, const unsi
 // the unrolled rows instead cost hundreds of register copies per column).
 template <int MR, int NX>
 SMX_HD void prescan_dp(const unsigned *planes, unsigned *scratch, int lane, int g, int X, int CH, int ppr,
-                       const PreDesc &D, int p, PreRec (&out)[32]) {
+                       const PreDesc &D, int p, unsigned *wout, size_t cstride) {
     const int m = D.m[p], skip = MR - m, nsym = D.nsym;
+    (void)m;
     unsigned Pv[MR], Mv[MR];
     int aoff[MR];
 #pragma unroll
@@ -171,9 +203,6 @@ SMX_HD void prescan_dp(const unsigned *planes, unsigned *scratch, int lane, int 
         Pv[i] = i >= skip ? ~0u : 0u; Mv[i] = 0u;
         aoff[i] = (i >= skip ? (int)D.sym[p][i - skip] : PRE_MAXSYM) * 64 + lane;
     }
-    unsigned st[32];
-#pragma unroll
-    for (int r = 0; r < 32; r++) st[r] = 0u;
     unsigned xm[NX > 0 ? NX : 1][4];   // uniform: all-ones where extra symbol 4 + x contains A / C / T / G
 #pragma unroll
     for (int x = 0; x < (NX > 0 ? NX : 1); x++)
@@ -264,12 +293,15 @@ SMX_HD void prescan_dp(const unsigned *planes, unsigned *scratch, int lane, int 
             __builtin_amdgcn_sched_barrier(0);   // keep the live ranges column-sized: no hoisting of later columns' LDS reads
 #endif
         }
-        transpose32(fl);
+        transpose32(fl);   // -> one word per read: lt flags | e flags << 16 of this chunk
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint4 *dst = (uint4 *)(wout + (size_t)ch * cstride);
 #pragma unroll
-        for (int r = 0; r < 32; r++) fold16(fl[r], ch, st[r]);
+        for (int r = 0; r < 8; r++) dst[r] = make_uint4(fl[4 * r], fl[4 * r + 1], fl[4 * r + 2], fl[4 * r + 3]);
+#else
+        for (int r = 0; r < 32; r++) wout[(size_t)ch * cstride + r] = fl[r];
+#endif
     }
-#pragma unroll
-    for (int r = 0; r < 32; r++) out[r] = make_rec(st[r], m, (int)D.k[p]);
 }
 
 

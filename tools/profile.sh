@@ -16,5 +16,6 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SA
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \
     --output-format csv -d "$OUT/sq2" -- $BENCH > "$OUT/sq2.log" 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/misc" -- $BENCH > "$OUT/misc.log" 2>&1 || true
-python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.json"
-cat "$OUT/summary.json"
+python3 tools/summarize_prof.py "$OUT" demux_kernel > "$OUT/summary.json"
+python3 tools/summarize_prof.py "$OUT" prescan_kernel > "$OUT/summary_prescan.json"
+cat "$OUT/summary.json" "$OUT/summary_prescan.json"

@@ -10,7 +10,7 @@ import os
 import sys
 
 root = sys.argv[1]
-KERNEL = "demux_kernel"
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "demux_kernel"   # kernel name substring (prescan_kernel for the primer prescan)
 
 
 def pmc(sub):

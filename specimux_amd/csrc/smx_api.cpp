@@ -139,8 +139,9 @@ struct smx_panel {
     // the demux kernel, which then only redoes the alignments the prescan cannot take (smx_prescan_core.h)
     bool pre_ok = false;
     smx::PreDesc pre;
-    int pre_nw = 2, pre_mr = 24, pre_nx = 0, pre_blocks_per_cu = 1;
-    size_t pre_lds = 0;
+    int pre_mr = 24, pre_nx = 0, pre_blocks_t = 1, pre_blocks_d = 8;   // longest primer, degenerate symbols, residency
+    size_t pre_lds = 0;                      // transpose kernel staging
+    DevBuf pre_planes[SMX_MAX_STREAMS];      // per stream slot: the 2-bit text planes of the batch (read-tile major)
     DevBuf pre_recs[SMX_MAX_STREAMS];        // per stream slot: [2 * NP][search_len / 16][n_reads rounded up to a tile] flag words
     unsigned long long *d_phase = nullptr;   // SMX_PHASE_TIMING diagnostic
     int phase_grid = 0;
@@ -239,8 +240,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
         if (P->pre_ok) {
             P->pre_mr = maxm;
             P->pre_nx = P->pre.nsym - 4;
-            P->pre_nw = NP >= 4 ? 4 : 2;   // wave w aligns primers w, w + nw, ...
-            P->pre_lds = smx_prescan_lds_bytes(h.S, P->pre.nsym, P->pre_nw);
+            P->pre_lds = smx_prescan_lds_bytes(h.S);
             if (P->pre_lds > 160 * 1024) P->pre_ok = false;
         }
     }
@@ -397,6 +397,7 @@ void smx_panel_destroy(smx_panel *P) {
     if (P->d_tile_counter) (void)hipFree(P->d_tile_counter);
     for (auto &b : P->ws) b.release();
     for (auto &b : P->pre_recs) b.release();
+    for (auto &b : P->pre_planes) b.release();
     delete P;
 }
 
@@ -469,11 +470,13 @@ static int ensure_device(smx_panel *P) {
         P->blocks_per_cu_slots = occ;
     }
     if (P->pre_ok) {
-        if (P->pre_lds > 64 * 1024 && smx_prescan_set_lds_limit(P->pre_nw, P->pre_mr, P->pre_nx, P->pre_lds) != 0)
+        if (P->pre_lds > 64 * 1024 && smx_prescan_set_lds_limit(P->pre_lds) != 0)
             return fail(SMX_ERR_DEVICE, "cannot raise the prescan kernel's dynamic LDS limit to %zu bytes", P->pre_lds);
-        int occ = 0;
-        if (smx_prescan_occupancy(P->pre_nw, P->pre_mr, P->pre_nx, P->pre_lds, &occ) != 0 || occ < 1) occ = 1;
-        P->pre_blocks_per_cu = occ;
+        int occ_t = 0, occ_d = 0;
+        if (smx_prescan_occupancy(P->pre_mr, P->pre_nx, P->pre_lds, &occ_t, &occ_d) != 0 || occ_t < 1 || occ_d < 1) { occ_t = 1; occ_d = 8; }
+        P->pre_blocks_t = occ_t;
+        P->pre_blocks_d = occ_d;
+        if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] prescan: transpose %d workgroups/CU (lds %zu), DP %d waves/CU\n", occ_t, P->pre_lds, occ_d);
     }
     if (const char *e = getenv("SMX_BLOCKS_PER_CU")) P->blocks_per_cu = P->blocks_per_cu_slots = std::max(1, atoi(e));
     if (getenv("SMX_DEBUG")) {
@@ -530,16 +533,19 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     if (P->pre_ok) {
         npad = (n_reads + smx::PRE_TILE - 1) / smx::PRE_TILE * smx::PRE_TILE;
         const size_t need = (size_t)2 * P->hp.NP * (P->hp.S >> 4) * npad * sizeof(unsigned);
-        DevBuf &pb = P->pre_recs[slot];
-        if (need > pb.cap) {
-            if (pb.p) (void)hipStreamSynchronize((hipStream_t)stream);   // earlier launches on this stream still read it
+        DevBuf &pb = P->pre_recs[slot], &pp = P->pre_planes[slot];
+        const size_t need_planes = (size_t)(npad / smx::PRE_TILE) * (P->hp.S >> 4) * 8 * 64 * 4 * sizeof(unsigned);
+        if (need > pb.cap || need_planes > pp.cap) {
+            if (pb.p || pp.p) (void)hipStreamSynchronize((hipStream_t)stream);   // earlier launches on this stream still use them
             hipError_t pe = pb.ensure(need);
-            if (pe != hipSuccess) return fail(SMX_ERR_DEVICE, "prescan record buffer: %s", hipGetErrorString(pe));
+            if (pe == hipSuccess) pe = pp.ensure(need_planes);
+            if (pe != hipSuccess) return fail(SMX_ERR_DEVICE, "prescan buffers: %s", hipGetErrorString(pe));
         }
         const uint32_t ptiles = npad / smx::PRE_TILE;
-        const int pgrid = (int)std::min<uint32_t>(ptiles, (uint32_t)(P->n_cu * P->pre_blocks_per_cu));
-        int pe = smx_launch_prescan(&P->pre, P->pre_nw, P->pre_mr, P->pre_nx, pgrid, P->pre_lds, stream, d_windows, d_lens,
-                                    n_reads, P->hp.wstride, (unsigned *)pb.p, npad);
+        const int grid_t = (int)std::min<uint32_t>(ptiles, (uint32_t)(P->n_cu * P->pre_blocks_t));
+        const int grid_d = (int)std::min<uint32_t>(ptiles * (uint32_t)P->hp.NP, (uint32_t)(P->n_cu * P->pre_blocks_d));
+        int pe = smx_launch_prescan(&P->pre, P->pre_mr, P->pre_nx, grid_t, P->pre_lds, grid_d, stream, d_windows, d_lens, n_reads,
+                                    P->hp.wstride, (unsigned *)pp.p, (unsigned *)pb.p);
         if (pe != 0) return fail(SMX_ERR_DEVICE, "prescan kernel launch failed: %s", hipGetErrorString((hipError_t)pe));
         d_pre = (const unsigned *)pb.p;
     }

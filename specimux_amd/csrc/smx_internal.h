@@ -52,12 +52,12 @@ int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t 
                      uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts, smx_hit *d_hits, int8_t *d_bdist,
                      unsigned *d_tile_counter, int use_slots, const unsigned *d_pre, uint32_t npad);
 // primer prescan (smx_prescan.hip)
-size_t smx_prescan_lds_bytes(int S, int nsym, int nw);
-int smx_launch_prescan(const smx::PreDesc *D, int nw, int mr, int nx, int grid, size_t lds_bytes, void *stream,
-                       const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride, unsigned *d_out,
-                       uint32_t npad);
-int smx_prescan_set_lds_limit(int nw, int mr, int nx, size_t bytes);
-int smx_prescan_occupancy(int nw, int mr, int nx, size_t lds_bytes, int *blocks_per_cu);
+size_t smx_prescan_lds_bytes(int S);
+int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int grid_t, size_t lds_t, int grid_d, void *stream,
+                       const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride, unsigned *d_planes,
+                       unsigned *d_out);
+int smx_prescan_set_lds_limit(size_t bytes);
+int smx_prescan_occupancy(int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d);
 size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta, int kidx,
                            int slots, int bs);
 int smx_set_demux_lds_limit(int use64, size_t bytes);

@@ -1054,7 +1054,11 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         // every phase and ends up spilled to scratch (HBM traffic, reload latency); recomputing it is a few ALU ops
         asm volatile("" : "+v"(tid));
         const bool have = cur != 0xFFFFFFFFu;
-        if (tid == 0) aggr[9] = (int)atomicAdd(tile_counter, 1u);   // the tile to encode during this iteration
+        // the tile to encode during this iteration: the queue pop is issued here, its result is only parked in LDS after
+        // the barcode phases (a returning global atomic takes microseconds; storing it at once stalled wave 0, and with
+        // it the first barrier of every tile)
+        unsigned popped = 0;
+        if (tid == 0) popped = atomicAdd(tile_counter, 1u);
         const uint32_t r0 = have ? cur * R : 0u;
         const int nr = have ? (int)((n_reads - r0) < (uint32_t)R ? (n_reads - r0) : (uint32_t)R) : 0;
         const int nh = nr * H;
@@ -1089,8 +1093,10 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             // at the whole string) and the target [j_lo, Sp) -- at most search_len / 2 columns -- is scanned below.
             bool pre_done = false, pre_omatch = false;
             if (use_pre) {
-                const int bfull = prescan_decode(pre + (size_t)h * (S >> 4) * npad + r0 + (uint32_t)r, npad, S >> 4, MW, m, k, g.Sp,
-                                                 mrow, &jstar, &cnt);
+                const uint32_t gr = r0 + (uint32_t)r;   // flag words: [tile of 1024 reads][alignment h][chunk][read in tile]
+                const unsigned *pw = pre + ((size_t)(gr >> 10) * H + h) * (S >> 4) * PRE_TILE + (gr & (PRE_TILE - 1));
+                const int bfull = S == 80 ? prescan_decode<5>(pw, PRE_TILE, 5, MW, m, k, g.Sp, mrow, &jstar, &cnt)   // the default -l
+                                          : prescan_decode<0>(pw, PRE_TILE, S >> 4, MW, m, k, g.Sp, mrow, &jstar, &cnt);
                 pre_omatch = bfull <= k;
                 if (g.j_lo == 0) { pre_done = true; best = pre_omatch ? bfull : m + 1; }
                 else { jstar = 0; cnt = 0; }
@@ -1212,6 +1218,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 if (rflagC[divH(item)] == 0) primer_item(item, true);
                 else fbq[atomicAdd(&aggr[10], 1)] = (unsigned short)item;
             }
+#if defined(SMX_EXP) && SMX_EXP == 10
+            STAMP(3);   // timing experiment: wave 0's own pass-1 time lands in the "entries" slot
+#endif
             __syncthreads();
             const int nfb = aggr[10];
             for (int i = tid; i < nfb; i += NT) primer_item((int)fbq[i], false);
@@ -1618,6 +1627,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         // the encode target buffers: namask is OR-ed into, the next tile's orientation votes are counted up
         for (int i = tid; i < R * 2 * MW; i += NT) namask[i] = 0;
         for (int i = tid; i < R; i += NT) { ocnt[(par ^ 1) * R + i] = 0; rflag[(par ^ 1) * R + i] = 0; }
+        if (tid == 0) aggr[9] = (int)popped;
         __syncthreads();
         const uint32_t nxt = (uint32_t)aggr[9];
         STAMP(0);

@@ -1,13 +1,14 @@
-// smx_prescan.hip -- gfx950 kernel of the primer prescan (algorithm and phases: smx_prescan_core.h).
+// smx_prescan.hip -- gfx950 kernels of the primer prescan (algorithm: smx_prescan_core.h).
 //
-// One workgroup of NW waves per tile of 1024 reads (32 groups of 32).  LDS: the tile's 2-bit text planes
-// (2 * S / 16 blocks of 33 dwords per group: 42 KB at search_len 80) + a per-wave scratch of 2 x (nsym + 1) x 64 dwords
-// for the current / next column's base-occurrence words.  Three workgroups of two waves share a CU at S = 80.
-// Wave w aligns primers w, w + NW, ... (the pattern letters are wave-uniform: kernel-argument loads); its 64 lanes are
-// the tile's 32 groups x 2 ends.  A lane keeps the DP column (2 x rows), the rows' scratch addresses, the 5-plane gap
-// counter and the 32 flag words of the current 16-column chunk in registers:
-// ~200 VGPRs, two waves per SIMD.  Output: one flag word per (primer, end, 16-column chunk, read), layout
-// [primer * 2 + end][chunk][read] (prescan_decode turns the chunk words of one alignment into distance / ends).
+// prescan_transpose_kernel: one 256-thread workgroup per tile of 1024 reads (32 groups of 32); LDS = the tile's packed
+//   2-bit codes (2 * S / 16 blocks of 33 dwords per group: 42 KB at search_len 80); memory bound (reads the windows once).
+// prescan_dp_kernel: one wave per (tile, primer) -- the pattern letters are wave-uniform kernel-argument loads; its 64
+//   lanes are the tile's 32 groups x 2 ends.  No tile in LDS (a 4.6 KB scratch for the current / next column's
+//   base-occurrence words only): residency is set by registers.  A lane keeps the DP column (2 x rows), the rows' scratch
+//   addresses, the 5-plane gap counter, the 32 flag words of the current 16-column chunk and two four-column groups of
+//   plane words in registers.  Output: one flag word per (primer, end, 16-column chunk, read), layout
+//   [tile][primer * 2 + end][chunk][read in tile] (prescan_decode turns the chunk words of one alignment into
+//   distance / ends).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -15,101 +16,159 @@
 
 namespace smx {
 
-template <int NW, int MR, int NX>   // NX = extra (degenerate-letter) symbol rows; MR = DP rows compiled in: 24 when every primer has <= 24 nt, else 31 (one variant per kernel:
-                           // two DP bodies in one kernel made the register allocator spill hundreds of registers)
-__global__ __launch_bounds__(NW * 64, 2) void prescan_kernel(PreDesc D, const uint8_t *__restrict__ windows,
-                                                             const int32_t *__restrict__ lens, uint32_t n_reads, int stride, unsigned *__restrict__ out,
-                                                             uint32_t npad, uint32_t ntiles) {
+// ---- transpose kernel: windows -> 2-bit planes, bit-sliced over the 32 reads of a group (layout: prescan_plane_word)
+__global__ __launch_bounds__(256) void prescan_transpose_kernel(int S, const uint8_t *__restrict__ windows,
+                                                                const int32_t *__restrict__ lens, uint32_t n_reads, int stride,
+                                                                unsigned *__restrict__ gplanes, uint32_t ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned plds[];
-    constexpr int NT = NW * 64;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: the primer loop and the row switch are scalar branches
-    const int CH = D.S >> 4, ppr = 2 * CH;
+    constexpr int NT = 256;
+    const int tid = threadIdx.x;
+    const int CH = S >> 4, ppr = 2 * CH;
     unsigned *planes = plds;
-    unsigned *scratch = plds + PRE_G * ppr * PRE_BLK + 64 + wave * PRE_SCRATCH;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t r0 = tile * PRE_TILE;
-        // ---- phase 1: the tile's windows are one contiguous run of 16-byte pieces (stride = ppr * 16)
+        // ---- phase 1: the tile's windows are one contiguous run of 16-byte pieces (stride = ppr * 16): plain streaming
+        // loads, eight in flight per lane
         {
             const int npieces = PRE_TILE * ppr;
             int read = tid / ppr, c = tid - read * ppr;
             const int dr = NT / ppr, dc = NT - dr * ppr;
             const uint4 *src = (const uint4 *)(windows + (size_t)r0 * stride);
-#pragma unroll 8
-            for (int q = tid; q < npieces; q += NT) {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (r0 + (uint32_t)read < n_reads) {
-                    v = src[q];
-                    if (c < CH) {   // head window of a short read (rare): right-aligned, see prescan_short_head_piece
-                        const int L = lens[r0 + (uint32_t)read];
-                        if (L < D.S) {
-                            unsigned w4[4];
-                            prescan_short_head_piece(windows + (size_t)(r0 + (uint32_t)read) * stride, c, D.S, L, w4);
-                            v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                        }
+            if (r0 + PRE_TILE <= n_reads) {   // whole tile in range (all but the last): no per-load guard, so that the
+                                              // compiler keeps a batch of loads in flight instead of one per branch
+                // npieces = 1024 * ppr is a multiple of 8 * NT (ppr is even): eight unconditional loads per batch.  (With a
+                // bounds test per load the compiler waits for each load before it branches to the next: 40 serial round trips.)
+                for (int q0 = tid; q0 < npieces; q0 += 8 * NT) {
+                    uint4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = src[q0 + u * NT];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        prescan_store_piece(planes, read, c, ppr, v[u].x, v[u].y, v[u].z, v[u].w);
+                        read += dr; c += dc;
+                        if (c >= ppr) { c -= ppr; read++; }
                     }
                 }
-                prescan_store_piece(planes, read, c, ppr, v.x, v.y, v.z, v.w);
-                read += dr; c += dc;
-                if (c >= ppr) { c -= ppr; read++; }
+            } else {
+                for (int q = tid; q < npieces; q += NT) {
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (r0 + (uint32_t)read < n_reads) v = src[q];
+                    prescan_store_piece(planes, read, c, ppr, v.x, v.y, v.z, v.w);
+                    read += dr; c += dc;
+                    if (c >= ppr) { c -= ppr; read++; }
+                }
             }
         }
         __syncthreads();
-        // ---- phase 2: in-place bit transposes, one block per lane and round
-        for (int b = tid; b < PRE_G * ppr; b += NT) {
-            const int g = b / ppr;
-            prescan_transpose_block(planes, b, b - g * ppr, CH);
+        // ---- phase 1b: reads shorter than the window (rare): their head pieces again, right-aligned
+        // (prescan_short_head_piece); kept out of the streaming loop, where the length load would sit in front of a branch
+        {
+            int Ls[PRE_TILE / NT];
+#pragma unroll
+            for (int u = 0; u < PRE_TILE / NT; u++) {   // all length loads first
+                const uint32_t rd = r0 + (uint32_t)(tid + u * NT);
+                Ls[u] = lens[rd < n_reads ? rd : n_reads - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < PRE_TILE / NT; u++) {
+                const int read = tid + u * NT;
+                if (r0 + (uint32_t)read < n_reads && Ls[u] < S) {
+                    const uint8_t *row = windows + (size_t)(r0 + (uint32_t)read) * stride;
+                    for (int c = 0; c < CH; c++) {
+                        unsigned w4[4];
+                        prescan_short_head_piece(row, c, S, Ls[u], w4);
+                        prescan_store_piece(planes, read, c, ppr, w4[0], w4[1], w4[2], w4[3]);
+                    }
+                }
+            }
         }
         __syncthreads();
-        // ---- phase 3 + 4: this wave's primers
-        const int g = lane >> 1, X = lane & 1;
-        for (int p = wave; p < D.NP; p += NW) {
-            prescan_dp<MR, NX>(planes, scratch, lane, g, X, CH, ppr, D, p,
-                               out + (size_t)(2 * p + X) * CH * npad + r0 + (uint32_t)g * 32u, npad);
+        // ---- phase 2: bit transposes, one block per lane and round; 8 x 16-byte stores per block
+        uint4 *gp = (uint4 *)(gplanes + (size_t)tile * CH * 8 * 64 * 4);
+        for (int b2 = tid; b2 < PRE_G * ppr; b2 += NT) {   // b2 = c * 32 + g: 32 consecutive lanes store 32 consecutive groups
+            const int c = b2 >> 5, g = b2 & 31;
+            unsigned o[32];
+#if defined(SMX_EXP) && SMX_EXP == 11
+            for (int d = 0; d < 32; d++) o[d] = planes[(g * ppr + c) * PRE_BLK + d];   // timing experiment: no transpose (wrong planes, valid memory)
+#else
+            prescan_transpose_block(planes, g * ppr + c, c, CH, o);
+#endif
+            const int chunk = prescan_block_chunk(c, CH), lane = prescan_block_lane(g, c, CH);
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                gp[((size_t)chunk * 64 + lane) * 8 + q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
         }
-        __syncthreads();   // the next tile's phase 1 rewrites the planes
+        __syncthreads();   // the next tile's phase 1 rewrites the staging blocks
+    }
+}
+
+// ---- DP kernel: one wave per (tile, primer); NX = extra (degenerate-letter) symbol rows; MR = DP rows compiled in: 24
+// when every primer has <= 24 nt, else 31 (one variant per kernel: two DP bodies in one kernel made the register
+// allocator spill hundreds of registers)
+#ifndef SMX_PRE_WAVES
+#define SMX_PRE_WAVES 2   // waves per SIMD the DP kernel's register allocation aims at
+#endif
+template <int MR, int NX>
+__global__ __launch_bounds__(64, SMX_PRE_WAVES) void prescan_dp_kernel(PreDesc D, const unsigned *__restrict__ gplanes,
+                                                           unsigned *__restrict__ out, uint32_t ntiles) {
+    __shared__ unsigned scratch[PRE_SCRATCH];
+    const int lane = threadIdx.x;
+    const int CH = D.S >> 4;
+    const uint32_t nwork = ntiles * (uint32_t)D.NP;
+    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const uint32_t tile = wi / (uint32_t)D.NP;
+        const int p = (int)(wi - tile * (uint32_t)D.NP);
+        const int g = lane >> 1, X = lane & 1;
+        // tile-major output: the CH x 2 NP words of a read sit within its tile's 4 * 2 NP * CH KB
+        prescan_dp<MR, NX>(gplanes + (size_t)tile * CH * 8 * 64 * 4, scratch, lane, CH, D, p,
+                           out + ((size_t)tile * (2 * D.NP) + (size_t)(2 * p + X)) * CH * PRE_TILE + (uint32_t)g * 32u, PRE_TILE);
     }
 }
 
 }  // namespace smx
 
-extern "C" size_t smx_prescan_lds_bytes(int S, int nsym, int nw) {
-    return ((size_t)smx::PRE_G * (2 * (S >> 4)) * smx::PRE_BLK + 64 + (size_t)nw * smx::PRE_SCRATCH) * 4;
+extern "C" size_t smx_prescan_lds_bytes(int S) {   // the transpose kernel's staging blocks
+    return ((size_t)smx::PRE_G * (2 * (S >> 4)) * smx::PRE_BLK + 64) * 4;
 }
 
-#define SMX_PRE_VARIANTS(X)                                                                        \
-    X(2, 24, 0) X(2, 24, 4) X(2, 31, 0) X(2, 31, 4) X(4, 24, 0) X(4, 24, 4) X(4, 31, 0) X(4, 31, 4)
+#define SMX_PRE_VARIANTS(X) X(24, 0) X(24, 4) X(31, 0) X(31, 4)
 
-static const void *prescan_fn(int nw, int mr, int nx) {
-    const int mrv = mr <= 24 ? 24 : 31, nxv = nx > 0 ? 4 : 0, nwv = nw == 4 ? 4 : 2;
-#define X(NWV, MRV, NXV) if (nwv == NWV && mrv == MRV && nxv == NXV) return (const void *)smx::prescan_kernel<NWV, MRV, NXV>;
+static const void *prescan_fn(int mr, int nx) {
+    const int mrv = mr <= 24 ? 24 : 31, nxv = nx > 0 ? 4 : 0;
+#define X(MRV, NXV) if (mrv == MRV && nxv == NXV) return (const void *)smx::prescan_dp_kernel<MRV, NXV>;
     SMX_PRE_VARIANTS(X)
 #undef X
     return nullptr;
 }
 
-// nw = 2 or 4 waves per workgroup, mr = longest primer of the panel, nx = number of degenerate-letter symbols;
-// grid = resident workgroups (the caller sizes it)
-extern "C" int smx_launch_prescan(const smx::PreDesc *D, int nw, int mr, int nx, int grid, size_t lds_bytes, void *stream,
+// mr = longest primer of the panel, nx = largest number of degenerate-letter symbols of one primer;
+// grid_t / grid_d = resident workgroups of the two kernels (the caller sizes them)
+extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int grid_t, size_t lds_t, int grid_d, void *stream,
                                   const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride,
-                                  unsigned *d_out, uint32_t npad) {
+                                  unsigned *d_planes, unsigned *d_out) {
     static_assert(smx::PRE_MAXROWS == 31 && smx::PRE_MAXSYM == 8, "variant table");
     const uint32_t ntiles = (n_reads + smx::PRE_TILE - 1) / smx::PRE_TILE;
     hipStream_t s = (hipStream_t)stream;
-    const int mrv = mr <= 24 ? 24 : 31, nxv = nx > 0 ? 4 : 0, nwv = nw == 4 ? 4 : 2;
-#define X(NWV, MRV, NXV)                                                                                                  \
-    if (nwv == NWV && mrv == MRV && nxv == NXV)                                                                           \
-        hipLaunchKernelGGL((smx::prescan_kernel<NWV, MRV, NXV>), dim3(grid), dim3(NWV * 64), lds_bytes, s, *D, d_windows, \
-                           d_lens, n_reads, stride, d_out, npad, ntiles);
+    hipLaunchKernelGGL(smx::prescan_transpose_kernel, dim3(grid_t), dim3(256), lds_t, s, D->S, d_windows, d_lens, n_reads,
+                       stride, d_planes, ntiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const int mrv = mr <= 24 ? 24 : 31, nxv = nx > 0 ? 4 : 0;
+#define X(MRV, NXV)                                                                                            \
+    if (mrv == MRV && nxv == NXV)                                                                              \
+        hipLaunchKernelGGL((smx::prescan_dp_kernel<MRV, NXV>), dim3(grid_d), dim3(64), 0, s, *D, d_planes, d_out, ntiles);
     SMX_PRE_VARIANTS(X)
 #undef X
     return (int)hipGetLastError();
 }
 
-extern "C" int smx_prescan_set_lds_limit(int nw, int mr, int nx, size_t bytes) {
-    return (int)hipFuncSetAttribute(prescan_fn(nw, mr, nx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+extern "C" int smx_prescan_set_lds_limit(size_t bytes) {
+    return (int)hipFuncSetAttribute((const void *)smx::prescan_transpose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bytes);
 }
 
-extern "C" int smx_prescan_occupancy(int nw, int mr, int nx, size_t lds_bytes, int *blocks_per_cu) {
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, prescan_fn(nw, mr, nx), nw * 64, lds_bytes);
+extern "C" int smx_prescan_occupancy(int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d) {
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_t, (const void *)smx::prescan_transpose_kernel, 256, lds_t);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_d, prescan_fn(mr, nx), 64, 0);
 }

@@ -13,22 +13,25 @@
 // This header is host/device code: the kernel (smx_prescan.hip) and the CPU unit test (tests/cpu/prescan_sim.cpp) run
 // the same functions; on the host a "lane" is a loop index and LDS is a plain array.
 //
-// Per tile of PRE_G x 32 reads (one workgroup):
-//   phase 1  coalesced 16-byte loads of the windows; 16 ASCII bases -> one dword of 2-bit codes ((ch >> 1) & 3:
-//            A 0, C 1, T 2, G 3; 8 VALU per 16 bases), stored as 32 x 32 bit blocks [group][16-column chunk][read]
-//   phase 2  in-place 32 x 32 bit transposes: word (column, plane) over the 32 reads of the group; end A blocks (the
-//            head window) are stored reversed and complemented: the DP then sees revcomp(head) like the scalar scan
-//   phase 3  DP: lane = (group, end), primer uniform per wave.  Per column: the four base-occurrence words (and the
-//            unions a degenerate primer letter needs) go to a per-lane LDS scratch; row i reads its Eq word from a
-//            precomputed address (the pattern letter selects the scratch row): no per-cell select instruction.
-//            Unit-cost cell on the vertical / horizontal deltas (5 bit-ops), HW boundaries (top row free).
-//            Last-row bookkeeping: gap = score - running minimum as a 5-plane bit-sliced counter;
-//            lt = "new minimum here", e = "at the minimum here" -- two flag words per column.
-//            Every 16 columns the 16 lt + 16 e words are transposed back (one 32 x 32 transpose): one word per read =
-//            lt flags (bits 0-15) | e flags (bits 16-31) of the chunk's columns, written to HBM as
-//            [primer * 2 + end][chunk][read].  The consumer (prescan_decode, run by the demux kernel per alignment)
-//            needs nothing else: best = m - popcount(lt), jstar = last lt column (= first column at the final minimum),
-//            optimal ends = e flags from jstar on.
+// Two kernels, both over tiles of PRE_G x 32 reads:
+//   transpose kernel (one workgroup per tile, memory bound)
+//     phase 1  coalesced 16-byte loads of the windows; 16 ASCII bases -> one dword of 2-bit codes ((ch >> 1) & 3:
+//              A 0, C 1, T 2, G 3; 8 VALU per 16 bases), staged in LDS as 32 x 32 bit blocks [group][16-column chunk][read]
+//     phase 2  32 x 32 bit transposes in registers: word (column, plane) over the 32 reads of the group; end A blocks (the
+//              head window) reversed and complemented: the DP then sees revcomp(head) like the scalar scan.  The planes
+//              go to HBM as [tile][chunk][lane = group * 2 + end][32 words].
+//   DP kernel (one wave per (tile, primer); no tile in LDS, so residency is set by registers alone)
+//     lane = (group, end).  Per column: the four base-occurrence words (and the unions a degenerate primer letter
+//              needs) go to a per-lane LDS scratch; row i reads its Eq word from a precomputed address (the pattern
+//              letter selects the scratch row): no per-cell select instruction.
+//              Unit-cost cell on the vertical / horizontal deltas (5 bit-ops), HW boundaries (top row free).
+//              Last-row bookkeeping: gap = score - running minimum as a 5-plane bit-sliced counter;
+//              lt = "new minimum here", e = "at the minimum here" -- two flag words per column.
+//              Every 16 columns the 16 lt + 16 e words are transposed back (one 32 x 32 transpose): one word per read =
+//              lt flags (bits 0-15) | e flags (bits 16-31) of the chunk's columns, written to HBM as
+//              [tile][primer * 2 + end][chunk][read].  The consumer (prescan_decode, run by the demux kernel per
+//              alignment) needs nothing else: best = m - popcount(lt), jstar = last lt column (= first column at the
+//              final minimum), optimal ends = e flags from jstar on.
 #ifndef SMX_PRESCAN_CORE_H
 #define SMX_PRESCAN_CORE_H
 #include <stdint.h>
@@ -50,10 +53,11 @@ constexpr int PRE_SCRATCH = 2 * (PRE_MAXSYM + 1) * 64;   // dwords of per-wave s
 
 // Host-built description of the patterns (device copy passed by value to the kernel).
 struct PreDesc {
-    int NP, S, nsym, pure4;        // pure4: symbols 0..3 are exactly {A}, {C}, {T}, {G}
+    int NP, S, nsym, pure4;        // nsym = 4 + the largest number of degenerate-letter sets any one primer uses
     uint8_t m[64], k[64];
-    uint8_t symmask[PRE_MAXSYM];   // bit0 A, bit1 C, bit2 T, bit3 G (2-bit text code order)
-    uint8_t sym[64][32];           // pattern letter of row i of primer p, as a symbol index
+    uint8_t symmask[64][PRE_MAXSYM];   // per primer: symbol -> bit0 A, bit1 C, bit2 T, bit3 G (2-bit text code order);
+                                       // symbols 0..3 are {A}, {C}, {T}, {G}, the others that primer's degenerate letters
+    uint8_t sym[64][32];           // pattern letter of row i of primer p, as an index into its symbol table
 };
 
 // out[r] bit q = in[q] bit r
@@ -87,32 +91,41 @@ SMX_HD int pack_pl(int q) { return q & 1; }
 // ---- consumer side: one alignment from its CH chunk words (w[c * cstride], c = 0 .. CH-1).  Returns the best distance
 // (> k: no match) and, for a match, jstar, the number of optimal ends and the S-bit mask of optimal end columns
 // (mrow: MW = ceil(S / 32) words, bits below jstar cleared).
-// Only the first n_valid columns count (reads shorter than the window).
+// Only the first n_valid columns count (reads shorter than the window).  CHT > 0: chunk count known at compile time
+// (straight-line code: all loads first, no per-chunk branches); CHT = 0: run-time CH.
+template <int CHT>
 SMX_HD int prescan_decode(const unsigned *w, size_t cstride, int CH, int MW, int m, int k, int n_valid, unsigned *mrow,
                           int *jstar_out, int *nloc_out) {
     unsigned short *mrow16 = (unsigned short *)mrow;
     int nlt = 0, jstar = 0;
-    for (int c0 = 0; c0 < CH; c0 += 8) {
-        unsigned xs[8];   // all loads of a batch are issued before the first is used: one memory round trip, not eight
-#pragma unroll
-        for (int u = 0; u < 8; u++) xs[u] = c0 + u < CH ? w[(size_t)(c0 + u) * cstride] : 0u;
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int c = c0 + u;
-            if (c < CH) {
-                const int nv = n_valid - 16 * c;   // valid columns of this chunk
-                const unsigned keep = nv >= 16 ? 0xFFFFu : (nv > 0 ? (1u << nv) - 1u : 0u);
-                const unsigned x = xs[u] & (keep | (keep << 16));
-                const unsigned lt16 = x & 0xFFFFu;
+    auto chunk = [&](int c, unsigned xraw) {
+        const int nv = n_valid - 16 * c;   // valid columns of this chunk
+        const unsigned keep = nv >= 16 ? 0xFFFFu : (nv > 0 ? (1u << nv) - 1u : 0u);
+        const unsigned x = xraw & (keep | (keep << 16));
+        const unsigned lt16 = x & 0xFFFFu;
 #if defined(__HIP_DEVICE_COMPILE__)
-                nlt += __popc(lt16);
-                if (lt16) jstar = 16 * c + 31 - __clz((int)lt16);
+        nlt += __popc(lt16);
+        if (lt16) jstar = 16 * c + 31 - __clz((int)lt16);
 #else
-                nlt += __builtin_popcount(lt16);
-                if (lt16) jstar = 16 * c + 31 - __builtin_clz(lt16);
+        nlt += __builtin_popcount(lt16);
+        if (lt16) jstar = 16 * c + 31 - __builtin_clz(lt16);
 #endif
-                mrow16[c] = (unsigned short)(x >> 16);
-            }
+        mrow16[c] = (unsigned short)(x >> 16);
+    };
+    if (CHT > 0) {
+        unsigned xs[CHT > 0 ? CHT : 1];   // all loads are issued before the first is used: one memory round trip
+#pragma unroll
+        for (int c = 0; c < CHT; c++) xs[c] = w[(size_t)c * cstride];
+#pragma unroll
+        for (int c = 0; c < CHT; c++) chunk(c, xs[c]);
+        CH = CHT;
+    } else {
+        for (int c0 = 0; c0 < CH; c0 += 4) {
+            unsigned xs[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) xs[u] = c0 + u < CH ? w[(size_t)(c0 + u) * cstride] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (c0 + u < CH) chunk(c0 + u, xs[u]);
         }
     }
     if (CH & 1) mrow16[CH] = 0;
@@ -149,30 +162,43 @@ SMX_HD void prescan_store_piece(unsigned *planes, int read_in_tile, int c, int p
 // right-aligned (byte x of the S-byte head window <- head[x - (S - L)]) so that its reverse complement starts at column 0.
 SMX_HD void prescan_short_head_piece(const uint8_t *row, int c, int S, int L, unsigned (&w)[4]) {
     const int sh = S - (L < 0 ? 0 : L);
-    w[0] = w[1] = w[2] = w[3] = 0u;
-    for (int i = 0; i < 16; i++) {
-        const int x = 16 * c + i - sh;
-        if (x >= 0) w[i >> 2] |= (unsigned)row[x] << (8 * (i & 3));
+    const int x0 = 16 * c - sh;            // source byte of the piece's first byte (negative: before the window, reads as 0)
+    const int base = x0 & ~3, sh8 = (x0 & 3) * 8;
+    unsigned d[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {          // five aligned dwords cover the 16 bytes; all loads unconditional (clamped)
+        const int idx = base + 4 * k;
+        const int cl = idx < 0 ? 0 : (idx > S - 4 ? S - 4 : idx);
+        const unsigned v = *(const unsigned *)(row + cl);
+        d[k] = (idx >= 0 && idx <= S - 4) ? v : 0u;
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = sh8 ? (d[k] >> sh8) | (d[k + 1] << (32 - sh8)) : d[k];
 }
 
-// Phase 2, one block: transpose in place into DP order.  Pieces c < CH are the head window (end A: stored reversed and
-// complemented), pieces c >= CH the tail window (end B).  DP order: word 2 * t' + plane for DP column t' of the chunk.
-SMX_HD void prescan_transpose_block(unsigned *planes, int blk, int c, int CH) {
+// Phase 2, one block: 32 x 32 bit transpose, result in DP order.  Pieces c < CH are the head window (end A: reversed and
+// complemented), pieces c >= CH the tail window (end B).  DP order: out[2 * t' + plane] for DP column t' of the chunk.
+SMX_HD void prescan_transpose_block(const unsigned *planes, int blk, int c, int CH, unsigned (&out)[32]) {
     unsigned a[32];
-    unsigned *pb = planes + blk * PRE_BLK;
+    const unsigned *pb = planes + blk * PRE_BLK;
 #pragma unroll
     for (int r = 0; r < 32; r++) a[r] = pb[r];
     transpose32(a);
     const bool endA = c < CH;
-    const unsigned flip = endA ? ~0u : 0u;
 #pragma unroll
-    for (int q = 0; q < 32; q++) {
-        const int t = pack_t(q), pl = pack_pl(q);
-        const int dB = 2 * t + pl, dA = 2 * (15 - t) + pl;
-        pb[endA ? dA : dB] = pl ? (a[q] ^ flip) : a[q];
+    for (int d = 0; d < 32; d++) {   // word d = (DP column t' = d >> 1, plane d & 1); packed bit q = 8 * (t & 3) + 2 * (t >> 2) + plane
+        const int tB = d >> 1, tA = 15 - (d >> 1), pl = d & 1;
+        const unsigned wB = a[8 * (tB & 3) + 2 * (tB >> 2) + pl];
+        const unsigned wA = pl ? ~a[8 * (tA & 3) + 2 * (tA >> 2) + pl] : a[8 * (tA & 3) + 2 * (tA >> 2) + pl];
+        out[d] = endA ? wA : wB;
     }
 }
+// where block (g, c) of a tile lives in the HBM plane buffer: chunk, lane = g * 2 + end; its 32 words are contiguous
+// (128 bytes: whole cache lines for the transposing lane's eight 16-byte stores; the DP lane reads them back in four
+// pairs of 16-byte loads per chunk -- 40 load instructions per wave and tile, whatever their coalescing)
+SMX_HD int prescan_block_chunk(int c, int CH) { return c < CH ? CH - 1 - c : c - CH; }
+SMX_HD int prescan_block_lane(int g, int c, int CH) { return g * 2 + (c < CH ? 0 : 1); }
+SMX_HD size_t prescan_plane_word(int chunk, int lane, int d) { return ((size_t)chunk * 64 + lane) * 32 + d; }
 
 // Occurrence words of one text column -> this lane's scratch column (sc points at [buffer][symbol 0][lane]).
 // NX = extra symbol rows compiled in (0, or PRE_MAXSYM - 4 for panels with degenerate primer letters: unions of the four
@@ -186,14 +212,15 @@ SMX_HD void prescan_write_occ(unsigned *sc, unsigned b0, unsigned b1, const unsi
         sc[(4 + x) * 64] = (E0 & xm[x][0]) | (E1 & xm[x][1]) | (E2 & xm[x][2]) | (E3 & xm[x][3]);
 }
 
-// Phase 3: one lane = primer p against end X of group g's 32 reads.  `scratch` = this wave's PRE_SCRATCH dwords.
+// The DP: one lane = primer p against one (group, end) of the tile's reads: lane = group * 2 + end.  `gpl` = the tile's
+// planes in the HBM layout (prescan_plane_word), `scratch` = this wave's PRE_SCRATCH dwords of LDS.
 // MR = rows compiled in; a pattern of m <= MR rows occupies rows MR - m .. MR - 1.  The rows above it are inert: they
 // read the all-ones word of scratch row PRE_MAXSYM and start with a zero vertical delta, so every delta on them stays 0 and
 // the first pattern row sees the free top row of the HW alignment (straight-line code, no per-row branch; jumping into
 // the unrolled rows instead cost hundreds of register copies per column).
 template <int MR, int NX>
-SMX_HD void prescan_dp(const unsigned *planes, unsigned *scratch, int lane, int g, int X, int CH, int ppr,
-                       const PreDesc &D, int p, unsigned *wout, size_t cstride) {
+SMX_HD void prescan_dp(const unsigned *gpl, unsigned *scratch, int lane, int CH, const PreDesc &D, int p, unsigned *wout,
+                       size_t cstride) {
     const int m = D.m[p], skip = MR - m, nsym = D.nsym;
     (void)m;
     unsigned Pv[MR], Mv[MR];
@@ -207,27 +234,38 @@ SMX_HD void prescan_dp(const unsigned *planes, unsigned *scratch, int lane, int 
 #pragma unroll
     for (int x = 0; x < (NX > 0 ? NX : 1); x++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) xm[x][b] = (4 + x < nsym && ((D.symmask[4 + x] >> b) & 1)) ? ~0u : 0u;
+        for (int b = 0; b < 4; b++) xm[x][b] = ((D.symmask[p][4 + x] >> b) & 1) ? ~0u : 0u;   // unused symbols have an empty mask
     unsigned g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, zero = ~0u;   // gap = score - running minimum, starts at 0
     constexpr int bufw = PRE_SCRATCH / 2;   // compile-time buffer stride: the second buffer is an immediate offset
     unsigned *sc0 = scratch + lane, *sc1 = scratch + bufw + lane;
     sc0[PRE_MAXSYM * 64] = ~0u; sc1[PRE_MAXSYM * 64] = ~0u;   // the inert rows' Eq word (a row no symbol uses)
-    {   // prologue: column 0 of chunk 0
-        const unsigned *pb = planes + (g * ppr + (X ? CH : CH - 1)) * PRE_BLK;
-        prescan_write_occ<NX>(sc0, pb[0], pb[1], xm);
-    }
+    // plane words of the current and the next four-column group (8 words each: column t of a group = words 2t, 2t + 1),
+    // fetched one group ahead
+    unsigned pw[2][8];
+    auto fetch = [&](int grp, unsigned (&dst)[8]) {   // grp = chunk * 4 + group in chunk; two 16-byte loads per lane
+        const int chunk = grp >> 2, q = (grp & 3) * 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint4 *g4 = (const uint4 *)gpl;
+        const uint4 u0 = g4[((size_t)chunk * 64 + lane) * 8 + q], u1 = g4[((size_t)chunk * 64 + lane) * 8 + q + 1];
+        dst[0] = u0.x; dst[1] = u0.y; dst[2] = u0.z; dst[3] = u0.w; dst[4] = u1.x; dst[5] = u1.y; dst[6] = u1.z; dst[7] = u1.w;
+#else
+        for (int j = 0; j < 8; j++) dst[j] = gpl[prescan_plane_word(chunk, lane, 4 * q + j)];
+#endif
+    };
+    fetch(0, pw[0]);
+    prescan_write_occ<NX>(sc0, pw[0][0], pw[0][1], xm);   // prologue: column 0
     unsigned eqb[2][8];   // Eq words of the current / next row group
 #pragma unroll
     for (int u = 0; u < 8; u++) eqb[0][u] = scratch[aoff[u]];   // column 0, group 0 (16 * NG columns per chunk: even parity)
     for (int ch = 0; ch < CH; ch++) {
-        const unsigned *pb = planes + (g * ppr + (X ? CH + ch : CH - 1 - ch)) * PRE_BLK;
-        const unsigned *pbn = planes + (g * ppr + (X ? CH + ch + 1 : CH - 2 - ch)) * PRE_BLK;   // next chunk (unused after the last)
         unsigned fl[32];   // [0,16): lt flags, [16,32): e flags of this chunk's columns
 #pragma unroll
         for (int t = 0; t < 16; t++) {
+            const int gq = t >> 2, tq = t & 3, cur = gq & 1;   // four groups per chunk: the parity restarts with every chunk
+            if (tq == 0 && (ch * 4 + gq + 1 < CH * 4)) fetch(ch * 4 + gq + 1, pw[cur ^ 1]);
             // next column's occurrence words go to the other scratch buffer while this column's are read
-            if (t < 15) prescan_write_occ<NX>((t & 1) ? sc0 : sc1, pb[2 * t + 2], pb[2 * t + 3], xm);
-            else if (ch + 1 < CH) prescan_write_occ<NX>(sc0, pbn[0], pbn[1], xm);
+            if (tq < 3) prescan_write_occ<NX>((t & 1) ? sc0 : sc1, pw[cur][2 * tq + 2], pw[cur][2 * tq + 3], xm);
+            else if (ch * 4 + gq + 1 < CH * 4) prescan_write_occ<NX>((t & 1) ? sc0 : sc1, pw[cur ^ 1][0], pw[cur ^ 1][1], xm);
             const unsigned *sc = ((t & 1) ? scratch + bufw : scratch);
             unsigned Ph = 0u, Mh = 0u;   // HW: the top row is free
             // rows in groups of eight.  The Eq words of the NEXT group (of the next column after the last group: its
@@ -314,22 +352,24 @@ inline bool prescan_build_desc(PreDesc *D, int NP, int S, const char *const *pat
     D->NP = NP; D->S = S;
     static const char bases[4] = {'A', 'C', 'T', 'G'};   // 2-bit text code order
     D->nsym = 4;
-    for (int s = 0; s < 4; s++) D->symmask[s] = (uint8_t)(1u << s);
     for (int p = 0; p < NP; p++) {
         if (lens[p] < 1 || lens[p] > PRE_MAXROWS || ks[p] < 0 || ks[p] >= lens[p]) return false;
         D->m[p] = (uint8_t)lens[p];
         D->k[p] = (uint8_t)ks[p];
+        int ns = 4;
+        for (int s = 0; s < PRE_MAXSYM; s++) D->symmask[p][s] = s < 4 ? (uint8_t)(1u << s) : 0;
         for (int i = 0; i < lens[p]; i++) {
             unsigned mk = 0;
             for (int b = 0; b < 4; b++) if (eq((unsigned char)patterns[p][i], (unsigned char)bases[b])) mk |= 1u << b;
             int s = 0;
-            while (s < D->nsym && D->symmask[s] != mk) s++;
-            if (s == D->nsym) {
-                if (D->nsym == PRE_MAXSYM) return false;
-                D->symmask[D->nsym++] = (uint8_t)mk;
+            while (s < ns && D->symmask[p][s] != mk) s++;
+            if (s == ns) {
+                if (ns == PRE_MAXSYM) return false;   // more distinct degenerate letters in one primer than scratch rows
+                D->symmask[p][ns++] = (uint8_t)mk;
             }
             D->sym[p][i] = (uint8_t)s;
         }
+        if (ns > D->nsym) D->nsym = ns;
     }
     D->pure4 = D->nsym == 4;
     return true;

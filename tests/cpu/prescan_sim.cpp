@@ -114,7 +114,13 @@ int main(int argc, char **argv) {
         if (c < CH && rlen[read] < S) prescan_short_head_piece(&win[(size_t)read * 2 * S], c, S, rlen[read], w);
         prescan_store_piece(planes.data(), read, c, ppr, w[0], w[1], w[2], w[3]);
     }
-    for (int b = 0; b < PRE_G * ppr; b++) prescan_transpose_block(planes.data(), b, b % ppr, CH);   // phase 2
+    std::vector<unsigned> gpl((size_t)CH * 8 * 64 * 4, 0u);   // the tile's planes in the HBM layout
+    for (int b = 0; b < PRE_G * ppr; b++) {   // phase 2
+        const int g = b / ppr, c = b % ppr;
+        unsigned o[32];
+        prescan_transpose_block(planes.data(), b, c, CH, o);
+        for (int d = 0; d < 32; d++) gpl[prescan_plane_word(prescan_block_chunk(c, CH), prescan_block_lane(g, c, CH), d)] = o[d];
+    }
     std::vector<unsigned> scratch(PRE_SCRATCH);
     long bad = 0, checked = 0, matched = 0, multi = 0;
     const int MW = (S + 31) / 32;
@@ -122,8 +128,8 @@ int main(int argc, char **argv) {
     for (int p = 0; p < NP; p++)
         for (int lane = 0; lane < 64; lane++) {   // phase 3: lane = (group, end)
             const int g = lane >> 1, X = lane & 1;
-            if (D.m[p] <= 24) prescan_dp<24, PRE_MAXSYM - 4>(planes.data(), scratch.data(), lane, g, X, CH, ppr, D, p, words.data(), 32);
-            else prescan_dp<31, PRE_MAXSYM - 4>(planes.data(), scratch.data(), lane, g, X, CH, ppr, D, p, words.data(), 32);
+            if (D.m[p] <= 24) prescan_dp<24, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32);
+            else prescan_dp<31, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32);
             for (int r = 0; r < 32; r++) {
                 const int read = g * 32 + r;
                 std::string text;
@@ -145,7 +151,8 @@ int main(int argc, char **argv) {
                 // (2) the consumer's decode: distance, first optimal end, all optimal ends
                 unsigned mrow[9];
                 int jstar = -1, nloc = -1;
-                const int best = prescan_decode(words.data() + r, 32, CH, MW, m, ks[p], NV, mrow, &jstar, &nloc);
+                const int best = CH == 5 ? prescan_decode<5>(words.data() + r, 32, CH, MW, m, ks[p], NV, mrow, &jstar, &nloc)
+                                         : prescan_decode<0>(words.data() + r, 32, CH, MW, m, ks[p], NV, mrow, &jstar, &nloc);
                 if (best != run) ok = false;
                 if (run <= ks[p]) {
                     matched++;

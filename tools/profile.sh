@@ -17,5 +17,6 @@ rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS
     --output-format csv -d "$OUT/sq2" -- $BENCH > "$OUT/sq2.log" 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/misc" -- $BENCH > "$OUT/misc.log" 2>&1 || true
 python3 tools/summarize_prof.py "$OUT" demux_kernel > "$OUT/summary.json"
-python3 tools/summarize_prof.py "$OUT" prescan_kernel > "$OUT/summary_prescan.json"
-cat "$OUT/summary.json" "$OUT/summary_prescan.json"
+python3 tools/summarize_prof.py "$OUT" prescan_transpose_kernel > "$OUT/summary_prescan_transpose.json"
+python3 tools/summarize_prof.py "$OUT" prescan_dp_kernel > "$OUT/summary_prescan_dp.json"
+cat "$OUT/summary.json" "$OUT/summary_prescan_transpose.json" "$OUT/summary_prescan_dp.json"

@@ -187,6 +187,14 @@ int smx_batch_run_device(const smx_panel *panel, void *stream, const uint8_t *d_
                          uint32_t *d_n_extra, uint64_t *d_counts, smx_hit *d_hits, int8_t *d_bdist);
 
 /*
+ * Diagnostic: per-kernel device times of smx_batch_run_device on this panel.  enable != 0 makes every following launch
+ * record HIP events around its kernels (transpose, primer DP, demux) on the launch stream; with ms != NULL the call waits
+ * for the most recent instrumented launch and writes its three durations in milliseconds (0 for a kernel that did not
+ * run).  Off by default: the events cost a few microseconds per launch.
+ */
+int smx_debug_kernel_times(smx_panel *panel, int enable, float ms[3]);
+
+/*
  * Convenience wrapper over host buffers: allocates device scratch, copies, runs, copies back, synchronises.
  * counts is accumulated into (host, smx_counts_len() uint64).  Returns SMX_ERR_OVERFLOW if extra_cap was too
  * small (n_extra then holds the required capacity) or a read exceeded the per-read operation limit.
@@ -194,6 +202,27 @@ int smx_batch_run_device(const smx_panel *panel, void *stream, const uint8_t *d_
 int smx_batch_run(const smx_panel *panel, const uint8_t *windows, const int32_t *lens, uint32_t n_reads,
                   smx_op *ops, smx_op *extra, uint32_t extra_cap, uint32_t *n_extra, uint64_t *counts,
                   smx_hit *hits, int8_t *bdist);
+
+/*
+ * Lanes: the asynchronous host-buffer path (pinned, double-buffered hand-off).  A lane owns a HIP
+ * stream, page-locked host staging for one batch (windows + lengths in, records + counts out) and its device buffers.
+ * Pipelines keep two or three lanes in flight: while lane A's kernels run, lane B's windows cross PCIe and lane C's
+ * records are written out -- the replacement of the reference parent's pickled 1000-read batches
+ * (io_utils.py:429-450, orchestration.py:447-456).
+ *   smx_lane_create    max_reads = capacity of one batch
+ *   smx_lane_windows / smx_lane_lens   pinned staging the packer fills (smx_pack_windows_batch writes there directly)
+ *   smx_lane_submit    enqueue H2D copy, prescan + demux kernels, D2H copy on the lane's stream; returns at once
+ *   smx_lane_wait      block until the lane's batch is done; *ops / *extra point into the lane's pinned result buffers
+ *                      (valid until the next submit on this lane); counts (host, smx_counts_len() uint64) is accumulated
+ *                      into.  SMX_ERR_OVERFLOW as for smx_batch_run (the extra buffer of a lane holds max_reads records).
+ */
+typedef struct smx_lane smx_lane;
+int smx_lane_create(const smx_panel *panel, uint32_t max_reads, smx_lane **out);
+void smx_lane_destroy(smx_lane *lane);
+uint8_t *smx_lane_windows(smx_lane *lane);
+int32_t *smx_lane_lens(smx_lane *lane);
+int smx_lane_submit(smx_lane *lane, uint32_t n_reads);
+int smx_lane_wait(smx_lane *lane, const smx_op **ops, const smx_op **extra, uint32_t *n_extra, uint64_t *counts);
 
 /*
  * One edlib-equivalent alignment on the device (Myers bit-vector kernel), for unit parity with the oracle.
@@ -235,6 +264,9 @@ typedef struct smx_batch smx_batch;
 typedef struct smx_writer smx_writer;
 
 int smx_reader_open(const char *path, smx_reader **out, int *is_fastq);
+/* the records that START inside bytes [lo, hi) of an uncompressed 4-line FASTQ (multi-GPU sharding of one file: the
+ * ranges of all ranks partition the records); SMX_ERR_UNSUPPORTED for compressed, FASTA or irregular input */
+int smx_reader_open_range(const char *path, uint64_t lo, uint64_t hi, smx_reader **out, int *is_fastq);
 void smx_reader_close(smx_reader *reader);
 smx_batch *smx_batch_new(void);
 void smx_batch_free(smx_batch *batch);

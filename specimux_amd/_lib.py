@@ -57,6 +57,13 @@ SYMBOLS = [
     ("smx_pack_windows", C.c_int, [_P, _P, C.c_uint32, C.c_int32, _P, _P]),
     ("smx_batch_run_device", C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P, C.c_uint32, _P, _P, _P, _P]),
     ("smx_batch_run", C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, C.c_uint32, C.POINTER(C.c_uint32), _P, _P, _P]),
+    ("smx_debug_kernel_times", C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    ("smx_lane_create", C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
+    ("smx_lane_destroy", None, [_P]),
+    ("smx_lane_windows", _P, [_P]),
+    ("smx_lane_lens", _P, [_P]),
+    ("smx_lane_submit", C.c_int, [_P, C.c_uint32]),
+    ("smx_lane_wait", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_uint32), _P]),
     ("smx_align", C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                             C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     ("smx_comm_unique_id", C.c_int, [_P]),
@@ -65,6 +72,7 @@ SYMBOLS = [
     ("smx_comm_destroy", None, [_P]),
     # host streaming helpers
     ("smx_reader_open", C.c_int, [C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int)]),
+    ("smx_reader_open_range", C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(_P), C.POINTER(C.c_int)]),
     ("smx_reader_close", None, [_P]),
     ("smx_batch_new", _P, []),
     ("smx_batch_free", None, [_P]),

@@ -142,7 +142,9 @@ struct smx_panel {
     int pre_mr = 24, pre_nx = 0, pre_blocks_t = 1, pre_blocks_d = 8;   // longest primer, degenerate symbols, residency
     size_t pre_lds = 0;                      // transpose kernel staging
     DevBuf pre_planes[SMX_MAX_STREAMS];      // per stream slot: the 2-bit text planes of the batch (read-tile major)
-    DevBuf pre_recs[SMX_MAX_STREAMS];        // per stream slot: [2 * NP][search_len / 16][n_reads rounded up to a tile] flag words
+    DevBuf pre_recs[SMX_MAX_STREAMS];
+    hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};   // smx_debug_kernel_times: start, after transpose, after DP, end
+    bool kev_on = false, kev_pre = false;        // per stream slot: [2 * NP][search_len / 16][n_reads rounded up to a tile] flag words
     unsigned long long *d_phase = nullptr;   // SMX_PHASE_TIMING diagnostic
     int phase_grid = 0;
 };
@@ -398,6 +400,7 @@ void smx_panel_destroy(smx_panel *P) {
     for (auto &b : P->ws) b.release();
     for (auto &b : P->pre_recs) b.release();
     for (auto &b : P->pre_planes) b.release();
+    for (auto &e : P->kev) if (e) (void)hipEventDestroy(e);
     delete P;
 }
 
@@ -530,6 +533,7 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     // primer prescan in front of the demux kernel (same stream: ordered)
     const unsigned *d_pre = nullptr;
     uint32_t npad = 0;
+    if (P->kev_on) { (void)hipEventRecord(P->kev[0], (hipStream_t)stream); P->kev_pre = P->pre_ok; }
     if (P->pre_ok) {
         npad = (n_reads + smx::PRE_TILE - 1) / smx::PRE_TILE * smx::PRE_TILE;
         const size_t need = (size_t)2 * P->hp.NP * (P->hp.S >> 4) * npad * sizeof(unsigned);
@@ -545,15 +549,41 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         const int grid_t = (int)std::min<uint32_t>(ptiles, (uint32_t)(P->n_cu * P->pre_blocks_t));
         const int grid_d = (int)std::min<uint32_t>(ptiles * (uint32_t)P->hp.NP, (uint32_t)(P->n_cu * P->pre_blocks_d));
         int pe = smx_launch_prescan(&P->pre, P->pre_mr, P->pre_nx, grid_t, P->pre_lds, grid_d, stream, d_windows, d_lens, n_reads,
-                                    P->hp.wstride, (unsigned *)pp.p, (unsigned *)pb.p);
+                                    P->hp.wstride, (unsigned *)pp.p, (unsigned *)pb.p, P->kev_on ? (void *)P->kev[1] : nullptr);
         if (pe != 0) return fail(SMX_ERR_DEVICE, "prescan kernel launch failed: %s", hipGetErrorString((hipError_t)pe));
         d_pre = (const unsigned *)pb.p;
+        if (P->kev_on) (void)hipEventRecord(P->kev[2], (hipStream_t)stream);
     }
     uint32_t tiles = (n_reads + R - 1) / R;
     int grid = (int)std::min<uint32_t>(tiles, (uint32_t)(P->n_cu * (use_slots ? P->blocks_per_cu_slots : P->blocks_per_cu)));
     int e = smx_launch_demux(&P->hp, P->use64, R, grid, lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
                              extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, use_slots, d_pre, npad);
     if (e != 0) return fail(SMX_ERR_DEVICE, "demux kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (P->kev_on) (void)hipEventRecord(P->kev[3], (hipStream_t)stream);
+    return SMX_OK;
+}
+
+int smx_debug_kernel_times(smx_panel *P, int enable, float ms[3]) {
+    if (!P) return fail(SMX_ERR_ARG, "null argument");
+    if (ms) {
+        ms[0] = ms[1] = ms[2] = 0.f;
+        if (P->kev_on && P->kev[3]) {
+            HIP_TRY(hipEventSynchronize(P->kev[3]));
+            if (P->kev_pre) {
+                HIP_TRY(hipEventElapsedTime(&ms[0], P->kev[0], P->kev[1]));
+                HIP_TRY(hipEventElapsedTime(&ms[1], P->kev[1], P->kev[2]));
+                HIP_TRY(hipEventElapsedTime(&ms[2], P->kev[2], P->kev[3]));
+            } else {
+                HIP_TRY(hipEventElapsedTime(&ms[2], P->kev[0], P->kev[3]));
+            }
+        }
+    }
+    if (enable && !P->kev[0]) {
+        int rc = ensure_device(P);
+        if (rc) return rc;
+        for (auto &e : P->kev) HIP_TRY(hipEventCreate(&e));
+    }
+    P->kev_on = enable != 0;
     return SMX_OK;
 }
 
@@ -657,6 +687,129 @@ int smx_align(const char *query, int qlen, const char *target, int tlen, int k, 
                 cnt++;
             }
     *nloc = cnt;
+    return SMX_OK;
+}
+
+// ---- lanes: asynchronous host-buffer path (pinned staging, one stream per lane)
+struct smx_lane {
+    smx_panel *P = nullptr;
+    uint32_t cap = 0, n = 0;
+    hipStream_t stream = nullptr;
+    // pinned host staging
+    uint8_t *h_windows = nullptr;
+    int32_t *h_lens = nullptr;
+    smx_op *h_ops = nullptr, *h_extra = nullptr;
+    uint64_t *h_counts = nullptr;   // counts vector followed by one word holding n_extra
+    // device
+    uint8_t *d_windows = nullptr;
+    int32_t *d_lens = nullptr;
+    smx_op *d_ops = nullptr, *d_extra = nullptr;
+    uint64_t *d_counts = nullptr;   // same layout as h_counts
+    bool busy = false;
+};
+
+void smx_lane_destroy(smx_lane *L) {
+    if (!L) return;
+    if (L->stream) { (void)hipStreamSynchronize(L->stream); }
+    if (L->h_windows) (void)hipHostFree(L->h_windows);
+    if (L->h_lens) (void)hipHostFree(L->h_lens);
+    if (L->h_ops) (void)hipHostFree(L->h_ops);
+    if (L->h_extra) (void)hipHostFree(L->h_extra);
+    if (L->h_counts) (void)hipHostFree(L->h_counts);
+    if (L->d_windows) (void)hipFree(L->d_windows);
+    if (L->d_lens) (void)hipFree(L->d_lens);
+    if (L->d_ops) (void)hipFree(L->d_ops);
+    if (L->d_extra) (void)hipFree(L->d_extra);
+    if (L->d_counts) (void)hipFree(L->d_counts);
+    if (L->stream) (void)hipStreamDestroy(L->stream);
+    delete L;
+}
+
+int smx_lane_create(const smx_panel *Pc, uint32_t max_reads, smx_lane **out) {
+    smx_panel *P = const_cast<smx_panel *>(Pc);
+    if (!P || !out || max_reads == 0) return fail(SMX_ERR_ARG, "null argument");
+    int rc = ensure_device(P);
+    if (rc) return rc;
+    smx_lane *L = new smx_lane();
+    L->P = P;
+    L->cap = max_reads;
+    const size_t wb = (size_t)max_reads * P->hp.wstride, ob = (size_t)max_reads * sizeof(smx_op), cb = (smx_counts_len(P) + 1) * 8;
+#define LANE_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { smx_lane_destroy(L); return fail(SMX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); } } while (0)
+    LANE_TRY(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
+    LANE_TRY(hipHostMalloc((void **)&L->h_windows, wb, hipHostMallocDefault));
+    LANE_TRY(hipHostMalloc((void **)&L->h_lens, (size_t)max_reads * 4, hipHostMallocDefault));
+    LANE_TRY(hipHostMalloc((void **)&L->h_ops, ob, hipHostMallocDefault));
+    LANE_TRY(hipHostMalloc((void **)&L->h_extra, ob, hipHostMallocDefault));
+    LANE_TRY(hipHostMalloc((void **)&L->h_counts, cb, hipHostMallocDefault));
+    LANE_TRY(hipMalloc((void **)&L->d_windows, wb));
+    LANE_TRY(hipMalloc((void **)&L->d_lens, (size_t)max_reads * 4));
+    LANE_TRY(hipMalloc((void **)&L->d_ops, ob));
+    LANE_TRY(hipMalloc((void **)&L->d_extra, ob));
+    LANE_TRY(hipMalloc((void **)&L->d_counts, cb));
+#undef LANE_TRY
+    *out = L;
+    return SMX_OK;
+}
+
+uint8_t *smx_lane_windows(smx_lane *L) { return L ? L->h_windows : nullptr; }
+int32_t *smx_lane_lens(smx_lane *L) { return L ? L->h_lens : nullptr; }
+
+int smx_lane_submit(smx_lane *L, uint32_t n_reads) {
+    if (!L) return fail(SMX_ERR_ARG, "null argument");
+    if (L->busy) return fail(SMX_ERR_ARG, "lane already has a batch in flight: smx_lane_wait first");
+    HIP_TRY(hipSetDevice(L->P->device));   // lanes are driven from reader / writer threads: device selection is per thread
+    if (n_reads > L->cap) return fail(SMX_ERR_ARG, "batch of %u reads exceeds the lane capacity %u", n_reads, L->cap);
+    smx_panel *P = L->P;
+    const size_t ncnt = smx_counts_len(P);
+    L->n = n_reads;
+    HIP_TRY(hipMemsetAsync(L->d_counts, 0, (ncnt + 1) * 8, L->stream));
+    if (n_reads) {
+        HIP_TRY(hipMemcpyAsync(L->d_windows, L->h_windows, (size_t)n_reads * P->hp.wstride, hipMemcpyHostToDevice, L->stream));
+        HIP_TRY(hipMemcpyAsync(L->d_lens, L->h_lens, (size_t)n_reads * 4, hipMemcpyHostToDevice, L->stream));
+        int rc = smx_batch_run_device(P, L->stream, L->d_windows, L->d_lens, n_reads, L->d_ops, L->d_extra, L->cap,
+                                      (uint32_t *)(L->d_counts + ncnt), L->d_counts, nullptr, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(L->h_ops, L->d_ops, (size_t)n_reads * sizeof(smx_op), hipMemcpyDeviceToHost, L->stream));
+        // extra records are rare: the count is not known on the host yet, so a fixed small prefix travels with the batch and
+        // smx_lane_wait fetches the rest if there is more
+        HIP_TRY(hipMemcpyAsync(L->h_extra, L->d_extra, (size_t)std::min<uint32_t>(L->cap, std::max<uint32_t>(4096u, n_reads / 64)) * sizeof(smx_op),
+                               hipMemcpyDeviceToHost, L->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(L->h_counts, L->d_counts, (ncnt + 1) * 8, hipMemcpyDeviceToHost, L->stream));
+    L->busy = true;
+    return SMX_OK;
+}
+
+int smx_lane_wait(smx_lane *L, const smx_op **ops, const smx_op **extra, uint32_t *n_extra, uint64_t *counts) {
+    if (!L || !n_extra || !counts) return fail(SMX_ERR_ARG, "null argument");
+    if (!L->busy) return fail(SMX_ERR_ARG, "lane has no batch in flight");
+    smx_panel *P = L->P;
+    HIP_TRY(hipSetDevice(P->device));
+    const size_t ncnt = smx_counts_len(P);
+    L->busy = false;
+    {
+        hipError_t se = hipStreamSynchronize(L->stream);
+        if (se != hipSuccess) {
+            (void)hipMemset(P->d_tile_counter, 0, 64 * SMX_MAX_STREAMS);
+            return fail(SMX_ERR_DEVICE, "lane batch failed: %s", hipGetErrorString(se));
+        }
+    }
+    const uint32_t ne = (uint32_t)L->h_counts[ncnt];
+    *n_extra = ne;
+    if (L->h_counts[SMX_CNT_TOTAL] != L->n) {
+        (void)hipMemset(P->d_tile_counter, 0, 64 * SMX_MAX_STREAMS);
+        return fail(SMX_ERR_DEVICE, "demux kernel processed %llu of %u reads (tile queue out of step); counters reset",
+                    (unsigned long long)L->h_counts[SMX_CNT_TOTAL], L->n);
+    }
+    if (ne > L->cap) return fail(SMX_ERR_OVERFLOW, "extra buffer too small: need %u records, have %u", ne, L->cap);
+    const uint32_t sent = std::min<uint32_t>(L->cap, std::max<uint32_t>(4096u, L->n / 64));
+    if (ne > sent)   // the rest of the extra records
+        HIP_TRY(hipMemcpy(L->h_extra + sent, L->d_extra + sent, (size_t)(ne - sent) * sizeof(smx_op), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ncnt; i++) counts[i] += L->h_counts[i];
+    if (ops) *ops = L->h_ops;
+    if (extra) *extra = L->h_extra;
+    if (L->h_counts[SMX_CNT_OVERFLOW])
+        return fail(SMX_ERR_OVERFLOW, "%llu read(s) produced more than 16 write operations", (unsigned long long)L->h_counts[SMX_CNT_OVERFLOW]);
     return SMX_OK;
 }
 

@@ -127,6 +127,7 @@ struct smx_reader {
     bool gzfast = false, gz_eof = false;
     std::vector<char> carry;
     uint64_t upos = 0;
+    bool ranged = false;      // opened on a byte range: only the parallel plain-FASTQ engine can honour it
     bool gz_failed = false;   // sticky: a gzread error or a stream that ends inside a gzip member
     std::string gz_msg;
 
@@ -722,6 +723,51 @@ int smx_reader_open(const char *path, smx_reader **out, int *is_fastq) {
     return SMX_OK;
 }
 
+// First record start at or after byte `pos` of an uncompressed 4-line FASTQ (fd), or fsize if there is none.
+static int locate_record_start(int fd, uint64_t pos, uint64_t fsize, uint64_t *out) {
+    if (pos == 0) { *out = 0; return SMX_OK; }
+    if (pos >= fsize) { *out = fsize; return SMX_OK; }
+    for (uint64_t span = 4u << 20;; span *= 4) {
+        const uint64_t a = pos - 1, len = std::min<uint64_t>(span, fsize - a);
+        std::vector<char> buf(len);
+        uint64_t got = 0;
+        while (got < len) {
+            ssize_t k = pread(fd, buf.data() + got, (size_t)(len - got), (off_t)(a + got));
+            if (k < 0) { if (errno == EINTR) continue; return smx_set_error(SMX_ERR_ARG, "read: %s", strerror(errno)); }
+            if (k == 0) break;
+            got += (uint64_t)k;
+        }
+        const char *base = buf.data(), *end = base + got;
+        const char *nl = (const char *)memchr(base, '\n', got);   // the line that starts at or after pos begins after this
+        if (nl) {
+            const char *rs = find_record_start(nl + 1, end);
+            // find_record_start needs the record's three following lines in view: accept unless it ran into the buffer end
+            if (rs < end && (uint64_t)(end - rs) > 0) { *out = a + (uint64_t)(rs - base); return SMX_OK; }
+        }
+        if (a + got >= fsize) { *out = fsize; return SMX_OK; }   // nothing but a partial tail: belongs to the previous range
+    }
+}
+
+int smx_reader_open_range(const char *path, uint64_t lo, uint64_t hi, smx_reader **out, int *is_fastq) {
+    int rc = smx_reader_open(path, out, is_fastq);
+    if (rc) return rc;
+    smx_reader *r = *out;
+    if (!r->fast) {
+        smx_reader_close(r);
+        *out = nullptr;
+        return smx_set_error(SMX_ERR_UNSUPPORTED, "%s: byte ranges need an uncompressed FASTQ file", path);
+    }
+    uint64_t a = 0, b = r->fsize;
+    if (hi < lo) hi = lo;
+    rc = locate_record_start(r->fd, lo, r->fsize, &a);
+    if (!rc) rc = locate_record_start(r->fd, std::min<uint64_t>(hi, r->fsize), r->fsize, &b);
+    if (rc) { smx_reader_close(r); *out = nullptr; return rc; }
+    r->fpos = a;
+    r->fsize = b;        // the range is read like a file that ends at the first record start at or after hi
+    r->ranged = true;
+    return SMX_OK;
+}
+
 void smx_reader_close(smx_reader *r) {
     if (!r) return;
     if (r->gz) gzclose(r->gz);
@@ -768,6 +814,10 @@ int smx_reader_next(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_b
     if (r->fast) {
         int rc = next_fast(r, max_reads, max_bytes, b);
         if (rc < 0) return SMX_ERR_ARG;
+        if (rc == 0 && r->ranged) {
+            b->clear();
+            return smx_set_error(SMX_ERR_UNSUPPORTED, "%s: irregular FASTQ (wrapped lines?) cannot be read by byte range", r->path.c_str());
+        }
         if (rc == 0) {   // irregular FASTQ: continue with the general engine from this block's start, for good
             b->clear();
             r->fast = false;

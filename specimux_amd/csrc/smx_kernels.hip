@@ -1223,9 +1223,11 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 #endif
             __syncthreads();
             const int nfb = aggr[10];
-            for (int i = tid; i < nfb; i += NT) primer_item((int)fbq[i], false);
-            __syncthreads();
-            if (tid == 0) aggr[10] = 0;   // read by everyone before the barrier above; next written in the next tile's phase 2
+            if (nfb > 0) {   // uniform; usually nothing was queued and the tile goes straight on
+                for (int i = tid; i < nfb; i += NT) primer_item((int)fbq[i], false);
+                __syncthreads();
+                if (tid == 0) aggr[10] = 0;   // read by everyone before the barrier above; next written in the next tile's phase 2
+            }
         } else {
             for (int item = tid; item < nh; item += NT) primer_item(item, false);
             __syncthreads();

@@ -145,7 +145,7 @@ static const void *prescan_fn(int mr, int nx) {
 // grid_t / grid_d = resident workgroups of the two kernels (the caller sizes them)
 extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int grid_t, size_t lds_t, int grid_d, void *stream,
                                   const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride,
-                                  unsigned *d_planes, unsigned *d_out) {
+                                  unsigned *d_planes, unsigned *d_out, void *ev_mid) {
     static_assert(smx::PRE_MAXROWS == 31 && smx::PRE_MAXSYM == 8, "variant table");
     const uint32_t ntiles = (n_reads + smx::PRE_TILE - 1) / smx::PRE_TILE;
     hipStream_t s = (hipStream_t)stream;
@@ -153,6 +153,7 @@ extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int gri
                        stride, d_planes, ntiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
+    if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);   // diagnostic: boundary between the two kernels
     const int mrv = mr <= 24 ? 24 : 31, nxv = nx > 0 ? 4 : 0;
 #define X(MRV, NXV)                                                                                            \
     if (mrv == MRV && nxv == NXV)                                                                              \

@@ -37,6 +37,10 @@ class Batch:
         _lib.check(self._lib.smx_pack_windows_batch(self.handle, search_len, _lib.ptr(windows), _lib.ptr(lens)))
         return windows, lens
 
+    def pack_windows_into(self, search_len, windows, lens):
+        """Cut the end windows straight into caller-owned buffers (a Lane's pinned staging): no allocation, no copy."""
+        _lib.check(self._lib.smx_pack_windows_batch(self.handle, search_len, _lib.ptr(windows), _lib.ptr(lens)))
+
     def close(self):
         if self.handle:
             self._lib.smx_batch_free(self.handle)
@@ -49,12 +53,63 @@ class Batch:
             pass
 
 
+class Lane:
+    """One asynchronous batch slot of a panel (include/smx.h "Lanes"): page-locked staging + device buffers + a HIP stream.
+    `windows` / `lens` are numpy views of the pinned staging; submit() returns at once, wait() blocks and returns views
+    of the pinned result records (valid until the next submit on this lane)."""
+
+    def __init__(self, panel, max_reads):
+        self._lib = _lib.load()
+        self.panel = panel
+        self.max_reads = int(max_reads)
+        self.handle = C.c_void_p()
+        _lib.check(self._lib.smx_lane_create(panel.handle, self.max_reads, C.byref(self.handle)))
+        wp = C.cast(self._lib.smx_lane_windows(self.handle), C.POINTER(C.c_uint8))
+        lp = C.cast(self._lib.smx_lane_lens(self.handle), C.POINTER(C.c_int32))
+        self.windows = np.ctypeslib.as_array(wp, shape=(self.max_reads, panel.window_stride))
+        self.lens = np.ctypeslib.as_array(lp, shape=(self.max_reads,))
+        self.n = 0
+
+    def submit(self, n):
+        self.n = int(n)
+        _lib.check(self._lib.smx_lane_submit(self.handle, self.n))
+
+    def wait(self, counts):
+        """-> (ops, extra) numpy views; `counts` (uint64, panel.counts_len) is accumulated into."""
+        ops_p, extra_p, n_extra = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        _lib.check(self._lib.smx_lane_wait(self.handle, C.byref(ops_p), C.byref(extra_p), C.byref(n_extra), _lib.ptr(counts)))
+        if self.n == 0:
+            return np.zeros(0, dtype=_lib.OP_DTYPE), np.zeros(0, dtype=_lib.OP_DTYPE)
+        ops = np.ctypeslib.as_array(C.cast(ops_p, C.POINTER(C.c_uint8)), shape=(self.n * 32,)).view(_lib.OP_DTYPE)
+        if n_extra.value:
+            extra = np.ctypeslib.as_array(C.cast(extra_p, C.POINTER(C.c_uint8)), shape=(n_extra.value * 32,)).view(_lib.OP_DTYPE)
+        else:
+            extra = np.zeros(0, dtype=_lib.OP_DTYPE)
+        return ops, extra
+
+    def close(self):
+        if self.handle:
+            self._lib.smx_lane_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Reader:
-    def __init__(self, path):
+    def __init__(self, path, byte_range=None):
+        """byte_range = (lo, hi): only the records that start inside those bytes (uncompressed 4-line FASTQ)."""
         self._lib = _lib.load()
         self.handle = C.c_void_p()
         fq = C.c_int()
-        _lib.check(self._lib.smx_reader_open(path.encode(), C.byref(self.handle), C.byref(fq)))
+        if byte_range is None:
+            _lib.check(self._lib.smx_reader_open(path.encode(), C.byref(self.handle), C.byref(fq)))
+        else:
+            _lib.check(self._lib.smx_reader_open_range(path.encode(), int(byte_range[0]), int(byte_range[1]),
+                                                       C.byref(self.handle), C.byref(fq)))
         self.is_fastq = bool(fq.value)
 
     def next_batch(self, max_reads, max_bytes=0, into=None):

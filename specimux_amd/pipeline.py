@@ -1,9 +1,19 @@
 """Streaming file -> output-tree pipeline around the GPU hot path (the `-F` production mode).
 
 Replaces the reference's parent-parses / pool-of-workers structure (orchestration.py:153-237: serial
-SeqIO.parse, pickled 1000-read batches, per-worker lockf+fsync appends) with three overlapped stages in one
-process: native reader + window packer (thread), GPU batch run (main thread), native writer (thread).
-A batch owns its memory, so stage i+1 of batch k overlaps stage i of batch k+1."""
+SeqIO.parse, pickled 1000-read batches, per-worker lockf+fsync appends) with overlapped stages in one process:
+
+  reader thread   native reader -> parsed batch -> end windows cut STRAIGHT INTO a lane's page-locked staging
+                  (no per-batch allocation) -> lane.submit(): asynchronous H2D copy, prescan + demux kernels, D2H copy
+                  on the lane's own HIP stream
+  main thread     lane.wait() in submission order; counts accumulate
+  writer thread   native writer formats the records (views of the lane's pinned result buffers) and appends to the
+                  tree, then hands the lane back
+
+Three lanes are in flight: while lane A's kernels run, lane B's windows cross PCIe and lane C's records are being
+written (reference steps replaced: io_utils.py:429-450, orchestration.py:447-456).
+`byte_range` restricts the run to the records that START inside [lo, hi) of an uncompressed FASTQ (multi-GPU file
+sharding, specimux_amd/distributed.py)."""
 import os
 import queue
 import sys
@@ -13,20 +23,27 @@ import time
 import numpy as np
 
 from . import _lib
-from .native_io import Reader, Writer
+from .native_io import Lane, Reader, Writer
 
 BATCH_READS = 131072          # reads per kernel launch
 BATCH_BYTES = 256 << 20       # ... or this many bytes of input, whichever comes first
+N_LANES = 3
 
 
-def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seqs=-1, on_batch=None):
-    """Returns (total_reads, matched_reads, counts vector, is_fastq)."""
-    reader = Reader(sequence_file)
+def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seqs=-1, on_batch=None, byte_range=None,
+                  stats=None):
+    """Returns (total_reads, matched_reads, counts vector, is_fastq).  `stats` (dict), if given, receives the stage
+    seconds: read, pack, submit, gpu_wait (main thread blocked on a lane), write, close, wall."""
+    reader = Reader(sequence_file, byte_range=byte_range)
     writer = Writer(output_dir, prefix, reader.is_fastq, panel)
     counts = np.zeros(panel.counts_len, dtype=np.uint64)
-    q_in, q_out = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
+    lanes = [Lane(panel, BATCH_READS) for _ in range(N_LANES)]
+    free_lanes, q_gpu, q_out = queue.Queue(), queue.Queue(maxsize=N_LANES), queue.Queue(maxsize=N_LANES)
+    for ln in lanes:
+        free_lanes.put(ln)
     errors = []
-    timing = {"read": 0.0, "pack": 0.0, "gpu": 0.0, "write": 0.0} if os.environ.get("SMX_PIPELINE_TIMING") else None
+    timing = {"read": 0.0, "pack": 0.0, "submit": 0.0, "gpu_wait": 0.0, "write": 0.0, "close": 0.0}
+    n_delivered = [0]
     t_start = time.perf_counter()
 
     def produce():
@@ -39,7 +56,7 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                     break
                 to_skip -= len(b)
                 b.close()
-            while left is None or left > 0:
+            while (left is None or left > 0) and not errors:
                 want = BATCH_READS if left is None else min(BATCH_READS, left)
                 t0 = time.perf_counter()
                 b = reader.next_batch(want, BATCH_BYTES)
@@ -47,16 +64,24 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                     break
                 if left is not None:
                     left -= len(b)
+                n_delivered[0] += len(b)
                 t1 = time.perf_counter()
-                windows, lens = b.pack_windows(panel.search_len, panel.window_stride)
-                if timing:
-                    timing["read"] += t1 - t0
-                    timing["pack"] += time.perf_counter() - t1
-                q_in.put((b, windows, lens))
+                lane = free_lanes.get()
+                if lane is None:      # shutdown after an error elsewhere
+                    b.close()
+                    break
+                t2 = time.perf_counter()
+                b.pack_windows_into(panel.search_len, lane.windows, lane.lens)
+                t3 = time.perf_counter()
+                lane.submit(len(b))
+                timing["read"] += t1 - t0
+                timing["pack"] += t3 - t2
+                timing["submit"] += time.perf_counter() - t3
+                q_gpu.put((b, lane))
         except BaseException as e:   # surfaced in the main thread
             errors.append(e)
         finally:
-            q_in.put(None)
+            q_gpu.put(None)
 
     def consume():
         try:
@@ -64,15 +89,16 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                 item = q_out.get()
                 if item is None:
                     return
-                b, ops, extra = item
+                b, lane, ops, extra = item
                 t0 = time.perf_counter()
                 if not errors:
                     writer.write(b, ops, extra)
                 b.close()
-                if timing:
-                    timing["write"] += time.perf_counter() - t0
+                free_lanes.put(lane)
+                timing["write"] += time.perf_counter() - t0
         except BaseException as e:
             errors.append(e)
+            free_lanes.put(None)
             while q_out.get() is not None:   # keep draining so the main thread never blocks
                 pass
 
@@ -82,25 +108,39 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
     tc.start()
     try:
         while True:
-            item = q_in.get()
-            if item is None or errors:
+            item = q_gpu.get()
+            if item is None:
                 break
-            b, windows, lens = item
+            b, lane = item
+            if errors:
+                b.close()
+                continue
             t0 = time.perf_counter()
-            ops, extra, _ = panel.run(windows, lens, counts=counts)
-            if timing:
-                timing["gpu"] += time.perf_counter() - t0
-            q_out.put((b, ops, extra))
+            try:
+                ops, extra = lane.wait(counts)
+            except _lib.SmxError as e:
+                if e.code != _lib.ERR_OVERFLOW or "extra buffer" not in str(e):
+                    raise
+                # more extra records than a lane holds (pathological tie storms): this batch again, synchronously,
+                # with a buffer of the size the kernel asked for
+                ops, extra, _ = panel.run(lane.windows[:len(b)].copy(), lane.lens[:len(b)].copy(), counts=counts)
+            timing["gpu_wait"] += time.perf_counter() - t0
+            q_out.put((b, lane, ops, extra))
             if on_batch:
                 on_batch(int(counts[_lib.CNT_TOTAL]), int(counts[_lib.CNT_MATCHED]))
+    except BaseException as e:
+        errors.append(e)
     finally:
+        if errors:
+            free_lanes.put(None)
         q_out.put(None)
         tc.join()
         while tp.is_alive():   # unblock a producer stuck on a full queue after an error
             try:
-                q_in.get_nowait()
+                q_gpu.get_nowait()
             except queue.Empty:
                 pass
+            free_lanes.put(None)
             tp.join(timeout=0.05)
         reader.close()
     if errors:
@@ -108,11 +148,25 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
             writer.close()
         except Exception:
             pass
+        for ln in lanes:
+            try:
+                ln.close()
+            except Exception:
+                pass
         raise errors[0]
     t0 = time.perf_counter()
     writer.close()
-    if timing:
-        print("[smx pipeline] wall %.3f s: reader %.3f + pack %.3f (thread 1) | gpu %.3f (main) | writer %.3f + close %.3f "
-              "(thread 2)" % (time.perf_counter() - t_start, timing["read"], timing["pack"], timing["gpu"], timing["write"],
-                              time.perf_counter() - t0), file=sys.stderr)
+    timing["close"] = time.perf_counter() - t0
+    for ln in lanes:
+        ln.close()
+    timing["wall"] = time.perf_counter() - t_start
+    if int(counts[_lib.CNT_TOTAL]) != n_delivered[0]:
+        raise RuntimeError(f"pipeline accounting: the reader delivered {n_delivered[0]} reads, the kernels counted "
+                           f"{int(counts[_lib.CNT_TOTAL])}")
+    if stats is not None:
+        stats.update(timing)
+    if os.environ.get("SMX_PIPELINE_TIMING"):
+        print("[smx pipeline] wall %.3f s: reader %.3f + pack %.3f + submit %.3f (thread 1) | waiting for the GPU %.3f (main) | "
+              "writer %.3f + close %.3f (thread 2)" % (timing["wall"], timing["read"], timing["pack"], timing["submit"],
+                                                        timing["gpu_wait"], timing["write"], timing["close"]), file=sys.stderr)
     return int(counts[_lib.CNT_TOTAL]), int(counts[_lib.CNT_MATCHED]), counts, reader.is_fastq

@@ -91,7 +91,9 @@ def setup_logging(debug: bool, output_dir: str = None, is_worker: bool = False):
 def main(argv=None):
     argv = sys.argv if argv is None else argv
     args = parse_args(argv)
-    setup_logging(args.debug, args.output_dir if args.output_to_files else None)
+    # under a one-process-per-GPU launch (torch.distributed.run) only rank 0 owns log.txt (the reference's workers log
+    # to the console only: multiprocessing_utils.py)
+    setup_logging(args.debug, args.output_dir if args.output_to_files else None, is_worker=int(os.environ.get("RANK", "0")) > 0)
     logging.info(f"Starting {version()}")
     logging.info(f"Command line: {' '.join(argv)}")
     from . import orchestration

@@ -224,9 +224,34 @@ def _run_native(args):
     from .pipeline import run_streaming
     specimens, parameters, prefilter = _load(args)
     args.isfastq = detect_file_format(args.sequence_file) == "fastq"
-    create_output_files(args, specimens)
+    from .distributed import env_rank
+    rank, _local, world = env_rank()
+    if rank == 0:
+        create_output_files(args, specimens)
     start = timeit.default_timer()
     panel = compiled_panel(specimens, parameters, args, prefilter)
+    if world > 1:
+        # one process per GPU (python -m torch.distributed.run ... -m specimux_amd.cli ...): the input file is cut
+        # into byte ranges at record boundaries, every rank writes its own tree, one RCCL all-reduce sums the counts,
+        # rank 0 merges (specimux_amd/distributed.py; reference: the worker pool of orchestration.py:181-207)
+        if args.start_seq > 1 or args.num_seqs >= 0:
+            raise ValueError("-n/--num-seqs windows are not supported together with multi-GPU sharding")
+        from .distributed import run_sharded
+
+        def shard_runner(seqfile, out_dir, byte_range, stride):
+            t, m, c, _fq = run_streaming(seqfile, panel, out_dir, args.output_file_prefix, byte_range=byte_range, stride=stride)
+            return t, m, c
+
+        total, matched, _counts, _w = run_sharded(args.sequence_file, args.output_dir, args.output_file_prefix,
+                                                  panel.counts_len, shard_runner)
+        if rank == 0:
+            logging.info(f"Demultiplexed on {world} GPUs (read-sharded by byte range, counts summed by all-reduce)")
+            _finish(total, matched, start)
+            cleanup_empty_directories(args.output_dir)
+            if getattr(args, "sample_topq", 0) > 0:
+                subsample_top_quality(args.output_dir, args.sample_topq)
+            cleanup_locks(args.output_dir)
+        return
     total, matched, _counts, _fq = run_streaming(args.sequence_file, panel, args.output_dir, args.output_file_prefix,
                                                  start_seq=args.start_seq, num_seqs=args.num_seqs)
     _finish(total, matched, start)

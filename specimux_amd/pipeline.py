@@ -31,10 +31,11 @@ N_LANES = 3
 
 
 def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seqs=-1, on_batch=None, byte_range=None,
-                  stats=None):
+                  stats=None, stride=None):
     """Returns (total_reads, matched_reads, counts vector, is_fastq).  `stats` (dict), if given, receives the stage
     seconds: read, pack, submit, gpu_wait (main thread blocked on a lane), write, close, wall."""
     reader = Reader(sequence_file, byte_range=byte_range)
+    keep_batch = [0]   # stride = (rank, world): batch i belongs to rank i % world (inputs that cannot be cut by byte range)
     writer = Writer(output_dir, prefix, reader.is_fastq, panel)
     counts = np.zeros(panel.counts_len, dtype=np.uint64)
     lanes = [Lane(panel, BATCH_READS) for _ in range(N_LANES)]
@@ -64,6 +65,12 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                     break
                 if left is not None:
                     left -= len(b)
+                if stride is not None:
+                    mine = keep_batch[0] % stride[1] == stride[0]
+                    keep_batch[0] += 1
+                    if not mine:
+                        b.close()
+                        continue
                 n_delivered[0] += len(b)
                 t1 = time.perf_counter()
                 lane = free_lanes.get()
@@ -165,6 +172,10 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                            f"{int(counts[_lib.CNT_TOTAL])}")
     if stats is not None:
         stats.update(timing)
+    if os.environ.get("SMX_PIPELINE_STATS_JSON"):
+        import json
+        with open(os.environ["SMX_PIPELINE_STATS_JSON"], "w") as fh:
+            json.dump(timing, fh)
     if os.environ.get("SMX_PIPELINE_TIMING"):
         print("[smx pipeline] wall %.3f s: reader %.3f + pack %.3f + submit %.3f (thread 1) | waiting for the GPU %.3f (main) | "
               "writer %.3f + close %.3f (thread 2)" % (timing["wall"], timing["read"], timing["pack"], timing["submit"],

@@ -68,3 +68,87 @@ def test_two_rank_counts_reduce_equals_single_process(tmp_path):
     for rank in range(2):
         assert np.array_equal(np.load(tmp_path / f"counts_{rank}.npy"), whole)
     assert whole[0] == 40 and whole[1] == 6 and whole[8:].tolist() == [2, 3, 1]
+
+
+# ------------------------------------------------------------------ the FILE path: shard by byte range, per-rank trees, merge
+def _file_worker(rank, world, port, tmp, seqfile, pf, sf):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SMX_DIST_BACKEND="gloo")
+    from oracle import specimux_oracle as O
+    from parity_utils import Both
+    from specimux_amd import _lib
+    from specimux_amd.demultiplex import compiled_panel
+    from specimux_amd.distributed import run_sharded, stride_batches
+    from specimux_amd.native_io import Reader, Writer
+    from test_native_io_cpu import _ops_from_oracle
+    both = Both(pf, sf)
+    cp = compiled_panel(both.specimens, both.parameters, both.args, both.prefilter)   # host only: names + sharding metadata
+
+    def shard_runner(path, out_dir, byte_range, stride):
+        """The oracle stands in for the kernels (no GPU in this tier); reader, byte ranges, writer are the product's."""
+        reader = Reader(path, byte_range=byte_range)
+        writer = Writer(out_dir, "", reader.is_fastq, cp)
+        counts = np.zeros(cp.counts_len, dtype=np.uint64)
+        batches = stride_batches(reader, stride[0], stride[1], 300) if stride else iter(lambda: reader.next_batch(300), None)
+        for b in batches:
+            recs = [b.record(i) for i in range(len(b))]
+            ops, total, matched = O.process_sequences(recs, both.opar, both.opanel)
+            sops, extra = _ops_from_oracle(cp, ops, len(recs), {r[0]: i for i, r in enumerate(recs)})
+            writer.write(b, sops, extra)
+            counts[_lib.CNT_TOTAL] += total
+            counts[_lib.CNT_MATCHED] += matched
+            for op in ops:
+                if op.rtype in (O.R_FULL, O.R_DEREP) and op.sample_id in cp.specimen_ids:
+                    counts[_lib.CNT_SPECIMEN0 + cp.specimen_ids.index(op.sample_id)] += 1
+            b.close()
+        writer.close()
+        return int(counts[_lib.CNT_TOTAL]), int(counts[_lib.CNT_MATCHED]), counts
+
+    total, matched, gcounts, w = run_sharded(seqfile, os.path.join(tmp, "out"), "", cp.counts_len, shard_runner)
+    np.save(os.path.join(tmp, f"gcounts_{rank}.npy"), gcounts)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kind", ["fastq", "gz"])
+def test_two_rank_file_path_equals_single_process(tmp_path, kind):
+    """`specimux -F` under a 2-process launch: byte-range shards (stride fallback for gzip), per-rank trees, one
+    all-reduce of the counts, merge by rank 0.  The merged tree equals the single-process tree FILE BY FILE (records in
+    input order), and each specimen's counter equals the records in full/<pool>/<specimen>.fastq."""
+    import gzip
+    import shutil
+    from conftest import read_expected_tree
+    from oracle import specimux_oracle as O
+    from specimux_amd import _lib, synth
+    pan = synth.panel_c1()
+    pf, sf = pan.write(os.fspath(tmp_path / "panel"))
+    rs = synth.make_reads(pan, 1500, 77, windows_only=False)
+    seqfile = os.fspath(tmp_path / "reads.fastq")
+    rs.write_fastq(seqfile)
+    if kind == "gz":
+        with open(seqfile, "rb") as a, gzip.open(seqfile + ".gz", "wb") as b:
+            shutil.copyfileobj(a, b)
+        seqfile += ".gz"
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    mp.spawn(_file_worker, args=(2, port, os.fspath(tmp_path), seqfile, pf, sf), nprocs=2, join=True)
+    exp_tree, total, matched = O.run_files(pf, sf, seqfile)
+    got = {}
+    out = tmp_path / "out"
+    assert not any(p.name.startswith(".smx_rank_") for p in out.iterdir())   # rank trees merged and removed
+    for dirpath, _d, files in os.walk(out):
+        for fn in files:
+            full = os.path.join(dirpath, fn)
+            got[os.path.relpath(full, out)] = open(full).read()
+    if kind == "fastq":   # byte ranges keep the input order inside every file
+        assert got == {k: "".join(v) for k, v in exp_tree.items()}
+    else:                 # stride sharding interleaves batches: same records, file by file
+        assert {k: sorted(v.split("@read")) for k, v in got.items()} == {k: sorted("".join(v).split("@read")) for k, v in exp_tree.items()}
+    g0, g1 = np.load(tmp_path / "gcounts_0.npy"), np.load(tmp_path / "gcounts_1.npy")
+    assert np.array_equal(g0, g1) and int(g0[_lib.CNT_TOTAL]) == total == 1500 and int(g0[_lib.CNT_MATCHED]) == matched
+    panel = O.load_panel(pf, sf)
+    for i, spec in enumerate(panel.specimens):
+        path = out / "full" / spec[1] / f"{spec[0]}.fastq"
+        n_rec = path.read_text().count("\n") // 4 if path.exists() else 0
+        assert int(g0[_lib.CNT_SPECIMEN0 + i]) == n_rec, spec[0]
+    assert int(g0[_lib.CNT_SPECIMEN0:].sum()) > 500

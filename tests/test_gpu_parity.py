@@ -475,6 +475,40 @@ def test_cli_end_to_end_synthetic(lib, c2, tmp_path, variant):
     assert f"Processed {total:,} sequences, match rate: {matched / total:.1%}" in log
 
 
+def test_cli_two_rank_launch_equals_single_process(lib, c2, tmp_path):
+    """The product multi-GPU path for files, rehearsed with two ranks on this one GPU (gloo for the counts, since RCCL
+    refuses two ranks per device): `python -m torch.distributed.run --nproc-per-node 2 -m specimux_amd.cli ... -F`.
+    Byte-range shards, per-rank trees, merge: the tree is identical, file by file, to the single-process run."""
+    import os
+    import subprocess
+    import sys
+    from specimux_amd import cli, synth
+    from conftest import REPO
+    pan, (pf, sf) = c2
+    rs = synth.make_reads(pan, 3000, 515, windows_only=False)
+    fq = tmp_path / "reads.fastq"
+    rs.write_fastq(str(fq))
+    one = tmp_path / "one"
+    cli.main(["specimux", pf, sf, str(fq), "-F", "-O", str(one)])
+    two = tmp_path / "two"
+    env = dict(os.environ, SMX_DIST_BACKEND="gloo", PYTHONPATH=REPO)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                    "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), "-m", "specimux_amd.cli", pf, sf, str(fq),
+                    "-F", "-O", str(two)], check=True, env=env, timeout=600, cwd=REPO)
+
+    def tree(root):
+        out = {}
+        for dirpath, _d, files in os.walk(root):
+            for fn in files:
+                if fn != "log.txt":
+                    out[os.path.relpath(os.path.join(dirpath, fn), root)] = open(os.path.join(dirpath, fn)).read()
+        return out
+    a, b = tree(one), tree(two)
+    assert a == b and sum(1 for k in a if k.startswith("full/")) > 100
+    log = (two / "log.txt").read_text()
+    assert "Demultiplexed on 2 GPUs" in log and "Processed 3,000 sequences" in log
+
+
 # ------------------------------------------------------------------ panel shapes that select other kernel paths
 def _custom_panel(tmp_path_factory, name, n_fwd, n_rev, bc_len, min_dist, fwd_primer=None, mixed=False, seed=7):
     from specimux_amd import synth

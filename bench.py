@@ -95,7 +95,7 @@ def host_cores():
     return min(n, 64)
 
 
-def cpu_baseline(pf, sf, rs, e2e_dir, budget_reads_per_core=8000, file_reads_per_core=3000):
+def cpu_baseline(pf, sf, rs, e2e_dir, budget_reads_per_core=32000, file_reads_per_core=8000):
     """Reference-shaped CPU path (the oracle) on bounded samples, all host cores, 1000-read batches like the
     reference's worker pool (orchestration.py:165).  Two scopes: in-memory reads (what `value` covers) and FASTQ files
     -> output trees (what `end_to_end` covers)."""

@@ -5,7 +5,7 @@
 set -e
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
-BENCH="python3 bench.py --no-cpu-baseline --steps 5 --warmup 2"
+BENCH="python3 bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 ${BENCH_ARGS:-}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/kt.log" 2>&1
@@ -19,4 +19,5 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d 
 python3 tools/summarize_prof.py "$OUT" demux_kernel > "$OUT/summary.json"
 python3 tools/summarize_prof.py "$OUT" prescan_transpose_kernel > "$OUT/summary_prescan_transpose.json"
 python3 tools/summarize_prof.py "$OUT" prescan_dp_kernel > "$OUT/summary_prescan_dp.json"
-cat "$OUT/summary.json" "$OUT/summary_prescan_transpose.json" "$OUT/summary_prescan_dp.json"
+python3 tools/make_pmc_summary.py "$OUT" > "$OUT/pmc_summary.json"
+cat "$OUT/pmc_summary.json"

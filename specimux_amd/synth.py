@@ -138,7 +138,7 @@ def _rc_rows(arr, lens):
     n, W = arr.shape
     j = np.arange(W)[None, :]
     src = np.clip(lens[:, None] - 1 - j, 0, W - 1)
-    comp = np.frombuffer(bytes.maketrans(b"ACGT", b"TGCA"), dtype=np.uint8)
+    comp = np.frombuffer(bytes.maketrans(b"ACGTN", b"TGCAN"), dtype=np.uint8)
     out = comp[np.take_along_axis(arr, src, axis=1)]
     out[j >= lens[:, None]] = 0
     return out
@@ -184,11 +184,17 @@ class ReadSet:
 CHUNK = 65536   # part of the generator's definition: chunk c of a read set uses default_rng([seed, c])
 
 
-def make_reads(panel: Panel, n, seed, **kw):
+def make_reads(panel: Panel, n, seed, workers=0, **kw):
     """n reads; generated in independent chunks of CHUNK reads so that memory stays bounded and the
-    result does not depend on how many reads are requested after a given chunk."""
-    parts = [_make_chunk(panel, min(CHUNK, n - lo), np.random.default_rng([seed, c]), **kw)
-             for c, lo in enumerate(range(0, n, CHUNK))]
+    result does not depend on how many reads are requested after a given chunk (nor on `workers`: chunk c always
+    uses default_rng([seed, c]); workers > 1 only runs chunks on a thread pool -- numpy releases the GIL)."""
+    jobs = [(min(CHUNK, n - lo), c) for c, lo in enumerate(range(0, n, CHUNK))]
+    if workers > 1 and len(jobs) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as ex:
+            parts = list(ex.map(lambda j: _make_chunk(panel, j[0], np.random.default_rng([seed, j[1]]), **kw), jobs))
+    else:
+        parts = [_make_chunk(panel, m, np.random.default_rng([seed, c]), **kw) for m, c in jobs]
     if len(parts) == 1:
         return parts[0]
     rs = ReadSet()
@@ -203,7 +209,7 @@ def make_reads(panel: Panel, n, seed, **kw):
 
 
 def _make_chunk(panel: Panel, n, rng, search_len=80, error_rate=0.06, insert_mean=650, insert_sd=120,
-                insert_min=200, insert_max=1500, windows_only=True):
+                insert_min=200, insert_max=1500, windows_only=True, n_frac=0.0):
     S = search_len
     K = S + 20   # insert bases generated on each side (enough to fill the window after deletions)
     npool = len(panel.pools)
@@ -268,6 +274,13 @@ def _make_chunk(panel: Panel, n, rng, search_len=80, error_rate=0.06, insert_mea
     # ---- errors
     hout, hlen = _apply_errors(rng, head, headlen, error_rate)
     tout, tlen = _apply_errors(rng, tail, taillen, error_rate)
+    if n_frac > 0:   # a share of the reads carries ambiguity codes ('N') inside the end windows
+        for out_, len_ in ((hout, hlen), (tout, tlen)):
+            sel = np.nonzero(rng.random(n) < n_frac)[0]
+            for k in range(3):
+                pos = rng.integers(0, np.maximum(len_[sel], 1))
+                ok = pos < len_[sel]
+                out_[sel[ok], pos[ok]] = 78
     ins = np.clip(rng.normal(insert_mean, insert_sd, n), max(insert_min, 2 * K), insert_max).astype(np.int32)
     middle = ins - 2 * K
     short = cat == 5

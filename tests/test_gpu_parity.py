@@ -400,6 +400,61 @@ def test_full_size_properties_765k(lib, c2):
     both.assert_ops_equal(reads, "765k sample")
 
 
+def _full_size_properties(cp, both, rs, S, n_specimens, label, sample=1500):
+    """Size-independent properties of one big batch + an oracle spot check (shared by the full-size config tests)."""
+    from specimux_amd import _lib
+    n = len(rs.lens)
+    windows = rs.windows(cp.window_stride)
+    ops, extra, counts = cp.run(windows, rs.lens)
+    assert counts[_lib.CNT_TOTAL] == n and counts[_lib.CNT_OVERFLOW] == 0
+    allops = np.concatenate([ops, extra])
+    assert len(allops) == counts[_lib.CNT_OPS_FULL] + counts[_lib.CNT_OPS_PARTIAL] + counts[_lib.CNT_OPS_UNKNOWN]
+    assert int(ops["n_ops"].sum()) == len(allops)
+    full = allops[(allops["rtype"] == _lib.R_DEREP_FULL) & ((allops["flags"] & _lib.OPF_TRIM_EMPTY) == 0)]
+    assert np.array_equal(np.bincount(full["sample"], minlength=n_specimens), counts[_lib.CNT_SPECIMEN0:].astype(np.int64))
+    assert counts[_lib.CNT_SPECIMEN0:].sum() == counts[_lib.CNT_OPS_FULL]
+    ops2, extra2, counts2 = cp.run(windows, rs.lens)                       # determinism / idempotence
+    assert np.array_equal(ops, ops2) and np.array_equal(counts, counts2)
+    rng = np.random.default_rng(99)
+    idx = np.sort(rng.choice(n, sample, replace=False))
+    both.assert_ops_equal(reads_from_set(rs, idx, S), f"{label} sample")
+    return counts
+
+
+def test_full_size_c3_5M(lib, c3):
+    """configs[2]: 3072 specimens over 4 pools (shared reverse primer, degenerate primers), 5 M reads in one batch on one
+    GPU: counter consistency, idempotence, and 1 500 seeded reads against the oracle record by record."""
+    from specimux_amd import _lib, synth
+    from specimux_amd.demultiplex import compiled_panel
+    pan, (pf, sf) = c3
+    both = Both(pf, sf)
+    cp = compiled_panel(both.specimens, both.parameters, both.args, both.prefilter)
+    rs = synth.make_reads(pan, 5_000_000, 3003, workers=16, insert_mean=900, insert_sd=250)
+    counts = _full_size_properties(cp, both, rs, 80, 3072, "c3 5M")
+    assert 0.5 < counts[_lib.CNT_MATCHED] / 5_000_000 < 0.9
+    per_pool = counts[_lib.CNT_SPECIMEN0:].reshape(4, 768).sum(axis=1)
+    assert per_pool.min() > 0.15 * per_pool.sum()                          # all four pools demultiplex
+
+
+def test_full_size_c5_stress_shape(lib, c3):
+    """configs[4]-shaped on one GPU: the 3072-specimen panel with degenerate primers, -l 160, 15 % error reads of 2-5 kb,
+    2 % of the reads with N inside the end windows: 1 M reads, properties + oracle sample."""
+    from specimux_amd import _lib, synth
+    from specimux_amd.demultiplex import compiled_panel
+    pan, (pf, sf) = c3
+    both = Both(pf, sf, search_len=160)
+    cp = compiled_panel(both.specimens, both.parameters, both.args, both.prefilter)
+    rs = synth.make_reads(pan, 1_000_000, 5005, workers=16, search_len=160, error_rate=0.15, insert_mean=3500, insert_sd=800,
+                          insert_min=2000, insert_max=5000, n_frac=0.02)
+    has_n = ((rs.head == 78) | (rs.tail == 78)).any(axis=1)
+    assert 0.02 < has_n.mean() < 0.06 and 2000 <= np.percentile(rs.lens, 10) and np.percentile(rs.lens, 90) <= 5600
+    counts = _full_size_properties(cp, both, rs, 160, 3072, "c5 1M", sample=800)
+    assert counts[_lib.CNT_MATCHED] / 1_000_000 > 0.2
+    # the N reads take the scalar primer scan (prescan fallback queue): a sample of them alone against the oracle
+    idx = np.nonzero(has_n)[0][:300]
+    both.assert_ops_equal(reads_from_set(rs, idx, 160), "c5 N reads")
+
+
 def test_counts_allreduce_single_rank(lib):
     """RCCL wrapper of the C ABI with a world of one (the multi-rank path is exercised by bench.py --gpus N)."""
     import torch

@@ -233,6 +233,18 @@ int smx_align(const char *query, int qlen, const char *target, int tlen, int k, 
               int *dist, int *starts, int *ends, int cap, int *nloc);
 
 /*
+ * N alignments in one launch (trace level 3 and --color ask for thousands per batch; device workspace is cached).
+ *   queries / qoff      n_queries distinct query strings (concatenated, n_queries + 1 offsets), each 1..64 letters
+ *   targets / toff      n targets (concatenated, n + 1 offsets), each >= 1 letter
+ *   qidx, k, mode       per alignment: query index, max distance, 0 = HW / 1 = SHW
+ *   dist, nloc          per alignment: best distance (-1: above k) and number of optimal locations
+ *   starts, ends        n x cap; the first min(nloc, cap) locations of alignment i at [i * cap ..)
+ */
+int smx_align_batch(const char *queries, const uint32_t *qoff, uint32_t n_queries, const char *targets,
+                    const uint64_t *toff, const uint32_t *qidx, const int32_t *k, const uint8_t *mode, uint32_t n,
+                    int32_t *dist, int32_t *nloc, int32_t *starts, int32_t *ends, uint32_t cap);
+
+/*
  * RCCL reduction of the per-specimen counts over xGMI (one communicator per process/GPU).
  * smx_comm_unique_id fills a 128-byte id on rank 0; broadcast it by any means, then every rank calls
  * smx_comm_init.  smx_counts_allreduce sums d_counts (device pointer) in place across ranks.

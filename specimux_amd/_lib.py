@@ -66,6 +66,7 @@ SYMBOLS = [
     ("smx_lane_wait", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_uint32), _P]),
     ("smx_align", C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                             C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
+    ("smx_align_batch", C.c_int, [_P, _P, C.c_uint32, _P, _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P, C.c_uint32]),
     ("smx_comm_unique_id", C.c_int, [_P]),
     ("smx_comm_init", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     ("smx_counts_allreduce", C.c_int, [_P, C.c_size_t, _P, _P]),

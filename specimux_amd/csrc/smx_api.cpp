@@ -690,6 +690,67 @@ int smx_align(const char *query, int qlen, const char *target, int tlen, int k, 
     return SMX_OK;
 }
 
+// ---- batched alignments: grow-only device workspace shared by all calls (serialised)
+namespace {
+std::mutex g_align_mutex;
+DevBuf g_align_ws[12];
+}
+
+int smx_align_batch(const char *queries, const uint32_t *qoff, uint32_t n_queries, const char *targets, const uint64_t *toff,
+                    const uint32_t *qidx, const int32_t *k, const uint8_t *mode, uint32_t n, int32_t *dist, int32_t *nloc,
+                    int32_t *starts, int32_t *ends, uint32_t cap) {
+    if (!queries || !qoff || !targets || !toff || !qidx || !k || !mode || !dist || !nloc || (cap && (!starts || !ends)))
+        return fail(SMX_ERR_ARG, "null argument");
+    if (n == 0) return SMX_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SMX_ERR_DEVICE, "libsmx has no CPU path: no HIP device");
+    std::vector<unsigned long long> qpeq((size_t)n_queries * 32);
+    std::vector<int> qlen(n_queries);
+    std::string bad;
+    for (uint32_t q = 0; q < n_queries; q++) {
+        const int m = (int)(qoff[q + 1] - qoff[q]);
+        if (m < 1 || m > 64) return fail(SMX_ERR_UNSUPPORTED, "query %u: length %d outside 1..64", q, m);
+        std::string s(queries + qoff[q], m), r(s.rbegin(), s.rend());
+        if (!build_peq(s.data(), m, &qpeq[(size_t)q * 32], &bad) || !build_peq(r.data(), m, &qpeq[(size_t)q * 32 + 16], &bad))
+            return fail(SMX_ERR_UNSUPPORTED, "query %u: %s", q, bad.c_str());
+        qlen[q] = m;
+    }
+    const uint64_t tbytes = toff[n];
+    std::vector<unsigned char> codes(tbytes);
+    for (uint32_t i = 0; i < n; i++) {
+        if (toff[i + 1] <= toff[i]) return fail(SMX_ERR_UNSUPPORTED, "alignment %u: empty target", i);
+        if (qidx[i] >= n_queries || mode[i] > 1) return fail(SMX_ERR_ARG, "alignment %u: bad query index or mode", i);
+        if (k[i] < 0 || k[i] > 250) return fail(SMX_ERR_ARG, "alignment %u: bad max distance", i);
+    }
+    for (uint64_t j = 0; j < tbytes; j++) codes[j] = (unsigned char)code_of((unsigned char)targets[j]);
+    std::lock_guard<std::mutex> guard(g_align_mutex);
+    DevBuf *B = g_align_ws;
+    const size_t sz[11] = {qpeq.size() * 8, qlen.size() * 4, (size_t)n * 4, (size_t)tbytes, ((size_t)n + 1) * 8, (size_t)n * 4, (size_t)n,
+                           (size_t)tbytes, (size_t)n * 4, (size_t)n * 4, (size_t)n * cap * 4};
+    for (int b = 0; b < 11; b++) HIP_TRY(B[b].ensure(std::max<size_t>(sz[b], 16)));
+    HIP_TRY(B[11].ensure(std::max<size_t>(sz[10], 16)));
+    HIP_TRY(hipMemcpy(B[0].p, qpeq.data(), sz[0], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(B[1].p, qlen.data(), sz[1], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(B[2].p, qidx, sz[2], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(B[3].p, codes.data(), sz[3], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(B[4].p, toff, sz[4], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(B[5].p, k, sz[5], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(B[6].p, mode, sz[6], hipMemcpyHostToDevice));
+    int e = smx_launch_align_batch(nullptr, (const unsigned long long *)B[0].p, (const int *)B[1].p, (const unsigned *)B[2].p,
+                                   (const unsigned char *)B[3].p, (const unsigned long long *)B[4].p, (const int *)B[5].p,
+                                   (const unsigned char *)B[6].p, n, (unsigned char *)B[7].p, (int *)B[8].p, (int *)B[9].p,
+                                   (int *)B[10].p, (int *)B[11].p, cap);
+    if (e != 0) return fail(SMX_ERR_DEVICE, "alignment kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(dist, B[8].p, sz[8], hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(nloc, B[9].p, sz[9], hipMemcpyDeviceToHost));
+    if (cap) {
+        HIP_TRY(hipMemcpy(starts, B[10].p, sz[10], hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ends, B[11].p, sz[10], hipMemcpyDeviceToHost));
+    }
+    return SMX_OK;
+}
+
 // ---- lanes: asynchronous host-buffer path (pinned staging, one stream per lane)
 struct smx_lane {
     smx_panel *P = nullptr;

@@ -65,5 +65,9 @@ int smx_query_occupancy(int use64, int bsv, size_t lds_bytes, int *blocks_per_cu
 int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,
                      const unsigned char *d_tcodes, int n, int k, int mode, int *d_dist, unsigned char *d_endflag,
                      int *d_starts);
+int smx_launch_align_batch(void *stream, const unsigned long long *d_qpeq, const int *d_qlen, const unsigned *d_qidx,
+                           const unsigned char *d_tcodes, const unsigned long long *d_toff, const int *d_k,
+                           const unsigned char *d_modes, unsigned n, unsigned char *d_ws, int *d_dist, int *d_nloc,
+                           int *d_starts, int *d_ends, unsigned cap);
 }
 #endif

@@ -1841,6 +1841,54 @@ __global__ void align_kernel(const unsigned long long *peq, const unsigned long 
     }
 }
 
+// Many alignments per launch (smx_align_batch): one lane per alignment, the same column step.  q_peq: per distinct query
+// 32 words (Peq of the query, then Peq of the reversed query); the raw scores of alignment i go to ws[toff[i] ..).
+__global__ __launch_bounds__(64) void align_batch_kernel(const unsigned long long *__restrict__ q_peq, const int *__restrict__ q_len,
+                                                        const unsigned *__restrict__ qidx, const unsigned char *__restrict__ tcodes,
+                                                        const unsigned long long *__restrict__ toff, const int *__restrict__ kk,
+                                                        const unsigned char *__restrict__ modes, unsigned n, unsigned char *ws,
+                                                        int *__restrict__ out_dist, int *__restrict__ out_nloc,
+                                                        int *__restrict__ out_starts, int *__restrict__ out_ends, unsigned cap) {
+    const unsigned i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long *peq = q_peq + (size_t)qidx[i] * 32, *rpeq = peq + 16;
+    const int m = q_len[qidx[i]], k = kk[i], mode = modes[i], top = m - 1;
+    const unsigned char *t = tcodes + toff[i];
+    int nt = (int)(toff[i + 1] - toff[i]);
+    if (mode == 1 && nt > m + k) nt = m + k;   // SHW: an end beyond m + k costs more than k
+    unsigned char *sc = ws + toff[i];
+    unsigned long long Pv = ~0ull, Mv = 0;
+    int score = m, best = m + 1;
+    for (int j = 0; j < nt; j++) {
+        if (mode == 0) myers_step<unsigned long long, false>(peq[t[j]], Pv, Mv, score, top);
+        else myers_step<unsigned long long, true>(peq[t[j]], Pv, Mv, score, top);
+        best = score < best ? score : best;
+        sc[j] = (unsigned char)score;
+    }
+    if (best > k) { out_dist[i] = -1; out_nloc[i] = 0; return; }
+    out_dist[i] = best;
+    int cnt = 0;
+    for (int j = 0; j < nt; j++) {
+        if (sc[j] != (unsigned char)best) continue;
+        if ((unsigned)cnt < cap) {
+            int st = 0;
+            if (mode == 0) {   // edlib's start rule: last optimal position of the reversed problem
+                unsigned long long P2 = ~0ull, M2 = 0;
+                int s2 = m, lastc = 1;
+                for (int c = 1; c <= m + best && j - (c - 1) >= 0; c++) {
+                    myers_step<unsigned long long, true>(rpeq[t[j - (c - 1)]], P2, M2, s2, top);
+                    if (s2 == best) lastc = c;
+                }
+                st = j - (lastc - 1);
+            }
+            out_starts[(size_t)i * cap + cnt] = st;
+            out_ends[(size_t)i * cap + cnt] = j;
+        }
+        cnt++;
+    }
+    out_nloc[i] = cnt;
+}
+
 }  // namespace smx
 
 // ------------------------------------------------------------------------------------------------
@@ -1900,5 +1948,15 @@ extern "C" int smx_launch_align(void *stream, const unsigned long long *d_peq, c
                                 unsigned char *d_endflag, int *d_starts) {
     hipLaunchKernelGGL(smx::align_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_peq, d_rpeq, m, d_tcodes, n, k,
                        mode, d_dist, d_endflag, d_starts);
+    return (int)hipGetLastError();
+}
+
+extern "C" int smx_launch_align_batch(void *stream, const unsigned long long *d_qpeq, const int *d_qlen, const unsigned *d_qidx,
+                                      const unsigned char *d_tcodes, const unsigned long long *d_toff, const int *d_k,
+                                      const unsigned char *d_modes, unsigned n, unsigned char *d_ws, int *d_dist, int *d_nloc,
+                                      int *d_starts, int *d_ends, unsigned cap) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(smx::align_batch_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_qpeq, d_qlen, d_qidx,
+                       d_tcodes, d_toff, d_k, d_modes, n, d_ws, d_dist, d_nloc, d_starts, d_ends, cap);
     return (int)hipGetLastError();
 }

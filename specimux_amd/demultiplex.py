@@ -118,6 +118,61 @@ class _Locator:
         a, e = best.location()
         return (L - e - 1, L - a - 1) if reversed_sequence else (a, e)
 
+    def _ends(self, seq, rseq, rec, hits, bdist):
+        """(primer, hit index, searched string, bdist row) of the record's two ends, as locate() walks them."""
+        o = 1 if rec["flags"] & _lib.OPF_REVERSE else 0
+        for which, pi in ((1, int(rec["p1"])), (2, int(rec["p2"]))):
+            if pi < 0:
+                continue
+            primer = self.panel.primers[pi]
+            if which == 1:
+                h, sequence = pi * 2 + (0 if o == 0 else 1), (rseq if o == 0 else seq)
+            else:
+                h, sequence = pi * 2 + (1 if o == 0 else 0), (seq if o == 0 else rseq)
+            yield primer, sequence, bdist[h]
+
+    def prefetch(self, cache, seqs, ops, extra, hits, bdist):
+        """Collect the alignments locate() will request for this batch and run them in two launches."""
+        from .constants import AlignMode
+        S, stage1, pend = self.par.search_len, [], []
+        for i, rec in order_ops(ops, extra):
+            if (rec["flags"] & _lib.OPF_TRIM_EMPTY) or (rec["p1"] < 0 and rec["p2"] < 0):
+                continue
+            seq = seqs[i]
+            rseq = reverse_complement(seq)
+            L = len(seq)
+            for primer, sequence, bd_row in self._ends(seq, rseq, rec, hits[i], bdist[i]):
+                best_d = min((int(d) for d in bd_row[:len(primer.barcodes)] if d >= 0), default=-1)
+                if best_d < 0:
+                    continue
+                b = next(b for k_, b in enumerate(primer.barcodes) if bd_row[k_] == best_d)
+                s0 = L - S
+                s_ = 0 if s0 == -1 else s0
+                t = sequence[s_:L]
+                if not t:
+                    continue
+                req = (primer.primer_rc, t, int(self.par.max_dist_primers[primer.primer]), AlignMode.INFIX)
+                stage1.append(req)
+                pend.append((sequence, s_, reverse_complement(b), req))
+        cache.fill(stage1)
+        stage2 = []
+        for sequence, s_, b_rc, req in pend:
+            dist, locs = cache.table[req]
+            if dist < 0:
+                continue
+            L = len(sequence)
+            for _a, e in locs:
+                start = e + s_ + 1
+                if self.prefilter_on:
+                    x = sequence[start:][:self.pf_min]
+                    if len(x) < self.pf_min or any(ch not in "ACGT" for ch in x):
+                        continue
+                s2 = 0 if start == -1 else start
+                t = sequence[s2:L][:len(b_rc) + int(self.par.max_dist_index)]
+                if t:
+                    stage2.append((b_rc, t, int(self.par.max_dist_index), AlignMode.PREFIX))
+        cache.fill(stage2)
+
     def locate(self, seq, rseq, rec, hits, bdist, shift):
         """-> (p1, p2, b1, b2) locations of one record; `shift` = what trim_locations has subtracted so far."""
         L = len(seq)
@@ -162,6 +217,14 @@ def process_sequences(seq_records, parameters, specimens, args, prefilter, trace
     else:
         ops, extra, counts = panel.run(windows, lens)
     locator = _Locator(panel, parameters, _prefilter_enabled(prefilter)) if coloring else None
+    color_cache = None
+    if coloring:
+        # --color asks the device aligner for the best barcode's location of every painted end: all of them in two
+        # launches (primer windows, then barcode targets), found again by align_seq through the cache
+        from .alignment import AlignCache
+        color_cache = AlignCache()
+        locator.prefetch(color_cache, seqs, ops, extra, hits, bdist)
+        color_cache.__enter__()
     shifts = {}   # (read, candidate) -> accumulated trim_locations shift (Q8)
     write_ops: List[WriteOperation] = []
     rc_cache = {}
@@ -198,4 +261,6 @@ def process_sequences(seq_records, parameters, specimens, args, prefilter, trace
             quality_scores=[ord(c) - 33 for c in q], p1_location=locs[0], p2_location=locs[1], b1_location=locs[2],
             b2_location=locs[3], primer_pool=pool, p1_name=p1, p2_name=p2, resolution_type=rtype,
             trace_sequence_id=trace_ids.get(i)))
+    if color_cache is not None:
+        color_cache.__exit__(None, None, None)
     return write_ops, len(seq_records), int(counts[_lib.CNT_MATCHED])

@@ -137,6 +137,28 @@ def open_sequence_file(filename: str, args) -> Iterator[SeqRecord]:
     return gen()
 
 
+def native_sequence_records(filename: str, args, batch_reads: int = 65536) -> Iterator[SeqRecord]:
+    """The same iterator as open_sequence_file, parsed by the native streaming reader of libsmx.so (multi-threaded FASTQ
+    engine, gzip, FASTA): the record path of `-F -d` (trace diagnostics) reads its input through it."""
+    from .native_io import Reader
+    reader = Reader(filename)
+    args.isfastq = reader.is_fastq
+
+    def gen():
+        try:
+            while True:
+                b = reader.next_batch(batch_reads)
+                if b is None:
+                    return
+                for i in range(len(b)):
+                    rid, seq, qual = b.record(i)
+                    yield SeqRecord(seq, rid, rid, qual)
+                b.close()
+        finally:
+            reader.close()
+    return gen()
+
+
 def read_primers_file(filename: str) -> PrimerDatabase:
     registry = PrimerDatabase()
     with _open_text(filename) as fh:

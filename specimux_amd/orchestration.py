@@ -265,7 +265,11 @@ def _run_records(args, to_files: bool):
     """Record-object path (stdout mode, --color): Python parser + process_sequences + OutputManager."""
     from .demultiplex import process_sequences
     specimens, parameters, prefilter = _load(args)
-    seq_records = open_sequence_file(args.sequence_file, args)
+    if to_files:   # `-F -d`: trace events need record objects, but the input still comes through the native reader
+        from .io_utils import native_sequence_records
+        seq_records = native_sequence_records(args.sequence_file, args)
+    else:
+        seq_records = open_sequence_file(args.sequence_file, args)
     create_output_files(args, specimens)
     start = timeit.default_timer()
     if args.start_seq > 1:

@@ -522,23 +522,78 @@ class BatchReplayer:
         return sample_id, rt
 
 
+def _level3_requests(replayer, seqs, ops, hits, cache):
+    """The alignments `_end_events` will ask for at verbosity 3, for the whole batch: first every matched (read, primer,
+    end) over the search window, then -- from those locations -- every (barcode, location) attempt the exact-set prefilter
+    lets through.  Two launches instead of one per alignment."""
+    from .alignment import AlignMode
+    par, S = replayer.par, replayer.par.search_len
+    stage1 = []
+    ends = []   # (read index, string searched, primer, request)
+    for i, seq_str in enumerate(seqs):
+        if ops["rtype"][i] == _lib.R_FILTERED:
+            continue
+        L = len(seq_str)
+        rs_str = None
+        for pi, primer in enumerate(replayer.primers):
+            for X in (0, 1):
+                if hits[i][pi * 2 + X]["pdist"] < 0:
+                    continue
+                if X == 0 and rs_str is None:
+                    rs_str = reverse_complement(seq_str)
+                q = rs_str if X == 0 else seq_str
+                s0 = L - S
+                s_ = 0 if s0 == -1 else s0
+                t = q[s_:L]
+                if not t:
+                    continue
+                req = (primer.primer_rc, t, int(par.max_dist_primers[primer.primer]), AlignMode.INFIX)
+                stage1.append(req)
+                ends.append((q, s_, primer, req))
+    cache.fill(stage1)
+    stage2 = []
+    for q, s_, primer, req in ends:
+        dist, locs = cache.table[req]
+        if dist < 0:
+            continue
+        L = len(q)
+        for b in primer.barcodes:
+            b_rc = reverse_complement(b)
+            for _a, e in locs:
+                start = e + s_ + 1
+                if replayer.prefilter_on:
+                    x = q[start:][:replayer.pf_min]
+                    if len(x) < replayer.pf_min or any(ch not in "ACGT" for ch in x):
+                        continue
+                s2 = 0 if start == -1 else start
+                t = q[s2:L][:len(b_rc) + int(par.max_dist_index)]   # what align_seq keeps of a PREFIX target
+                if t:
+                    stage2.append((b_rc, t, int(par.max_dist_index), AlignMode.PREFIX))
+    cache.fill(stage2)
+
+
 def replay_batch(tl: TraceLogger, replayer: BatchReplayer, seq_records, seqs, ops, extra, hits, bdist, op_names,
                  record_offset: int):
     """Log every read of a batch; returns {read index: sequence_id} for the write operations."""
+    from .alignment import AlignCache
     by_read = {}
     for j in range(len(extra)):
         by_read.setdefault(int(extra["read"][j]), []).append(extra[j])
     ids = {}
-    for i, record in enumerate(seq_records):
-        sid = tl.get_sequence_id(record, record_offset + i)
-        ids[i] = sid
-        if ops["rtype"][i] == _lib.R_FILTERED:
-            recs = []
-        else:
-            recs = [ops[i]] + by_read.get(i, [])
-        rec_ops = []
-        for rec in recs:
-            sample, _pool, _p1, _p2, _code, rtype = op_names(replayer.panel, rec)
-            rec_ops.append((sample, rtype))
-        replayer.replay(tl, record, seqs[i], sid, hits[i], bdist[i], rec_ops)
+    cache = AlignCache()
+    if tl.verbosity >= 3:
+        _level3_requests(replayer, seqs, ops, hits, cache)
+    with cache:
+        for i, record in enumerate(seq_records):
+            sid = tl.get_sequence_id(record, record_offset + i)
+            ids[i] = sid
+            if ops["rtype"][i] == _lib.R_FILTERED:
+                recs = []
+            else:
+                recs = [ops[i]] + by_read.get(i, [])
+            rec_ops = []
+            for rec in recs:
+                sample, _pool, _p1, _p2, _code, rtype = op_names(replayer.panel, rec)
+                rec_ops.append((sample, rtype))
+            replayer.replay(tl, record, seqs[i], sid, hits[i], bdist[i], rec_ops)
     return ids

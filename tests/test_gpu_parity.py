@@ -65,6 +65,46 @@ def test_smx_align_matches_oracle(lib):
     assert n_checked == 600
 
 
+def test_smx_align_batch_matches_oracle(lib):
+    """smx_align_batch (one launch for thousands of alignments; what trace level 3 and --color use through
+    alignment.AlignCache) against the oracle's DP: distances and ALL optimal (start, end) locations, HW and SHW."""
+    from oracle import edlib_semantics as E
+    from specimux_amd.alignment import AlignCache, align_batch, align_seq
+    from specimux_amd.constants import AlignMode
+    rnd = random.Random(23)
+    alpha = "ACGT" * 8 + "NRYKMSWBDHV" + "ax"
+    qalpha = "ACGT" * 6 + "NRYKMSWBDHV"
+    reqs, exp = [], []
+    queries = ["".join(rnd.choice(qalpha) for _ in range(m)) for m in (1, 5, 13, 13, 20, 22, 31, 32, 33, 47, 64)]
+    for it in range(3000):
+        q = rnd.choice(queries)
+        m = len(q)
+        n = rnd.randint(1, 150)
+        t = "".join(rnd.choice(alpha) for _ in range(n))
+        if it % 2 == 0 and n > m:
+            pos = rnd.randint(0, n - m)
+            copy = list(q)
+            for _ in range(rnd.randint(0, 4)):
+                copy[rnd.randrange(m)] = rnd.choice("ACGT")
+            t = t[:pos] + "".join(copy) + t[pos + m:]
+        k = min(rnd.choice([0, 1, 3, 7, m - 1]), m - 1) if m > 1 else 0
+        mode = rnd.choice([AlignMode.INFIX, AlignMode.PREFIX])
+        reqs.append((q, t, k, mode))
+        e = E.align(q, t, E.HW if mode == AlignMode.INFIX else E.SHW, k)
+        exp.append((e["editDistance"], e["locations"]))
+    got = align_batch(reqs)
+    for r, g, e in zip(reqs, got, exp):
+        assert g[0] == e[0] and [tuple(x) for x in g[1]] == [tuple(x) for x in e[1]], (r, g, e)
+    # the cache path of align_seq returns what the single-call path returns
+    cache = AlignCache()
+    cache.fill([(q, (t[:len(q) + k] if mode == AlignMode.PREFIX else t), k, mode) for q, t, k, mode in reqs[:200]])
+    for q, t, k, mode in reqs[:200]:
+        direct = align_seq(q, t, k, 0, len(t), mode)
+        with cache:
+            cached = align_seq(q, t, k, 0, len(t), mode)
+        assert (direct.distance(), direct.locations()) == (cached.distance(), cached.locations())
+
+
 # ------------------------------------------------------------------ golden suite, through the GPU
 @pytest.mark.parametrize("seqfile", ["sequences.fastq", "sequences_rc.fastq"])
 def test_golden_hits_and_ops(lib, seqfile):

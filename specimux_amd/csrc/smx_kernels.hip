@@ -719,23 +719,35 @@ __device__ inline bool cand_has_specimen(const ReadCtx &c, const CandView &v, in
 // barcode tie".  Every dereplication group then has one member and the reference's machinery reduces to a
 // single emission.  Returns false for everything else (several best candidates, ties): the caller then runs
 // score_general, the reference's selection / dereplication in full, for that read.
-__device__ inline bool score_fast(Emitter &E, int ori) {
+// `G` lanes (a power of two, consecutive, `sub` = this lane's index among them) share one read: the candidate loops are
+// split over them and reduced by xor-shuffles (tiles of panels with many primers hold fewer than 64 reads, so the scorer
+// wave has lanes to spare, and with 10 candidates the loops are most of its instruction stream); everything after the
+// reductions -- one record in the usual case -- is done by sub-lane 0, the others return true at once.
+__device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
     const ReadCtx &c = *E.c;
     const DevPanel *P = c.P;
     // ---- select_best_matches (demultiplex.py:216-259): best score, how many carry it, the first of them
-    int best = 0, nbest = 0, only_pair = 0, only_o = 0;
-    for (int pair = 0; pair < P->NPAIR; pair++)
-        for (int o = 0; o < 2; o++) {
-            if ((o == 0 && ori == 2) || (o == 1 && ori == 1)) continue;
-            CandView v = cand_view(c, pair, o);
-            int sc = cand_score(v);
-            if (sc > best) { best = sc; nbest = 1; only_pair = pair; only_o = o; }
-            else if (sc == best) nbest++;
-        }
+    int best = 0, nbest = 0, first = 0x7FFF;
+    const int ncand = P->NPAIR * 2;
+    for (int ci = sub; ci < ncand; ci += G) {
+        const int pair = ci >> 1, o = ci & 1;
+        if ((o == 0 && ori == 2) || (o == 1 && ori == 1)) continue;
+        CandView v = cand_view(c, pair, o);
+        int sc = cand_score(v);
+        if (sc > best) { best = sc; nbest = 1; first = ci; }
+        else if (sc == best) { nbest++; first = ci < first ? ci : first; }
+    }
+    for (int d = 1; d < G; d <<= 1) {
+        const int ob = __shfl_xor(best, d, 64), on = __shfl_xor(nbest, d, 64), of = __shfl_xor(first, d, 64);
+        if (ob > best) { best = ob; nbest = on; first = of; }
+        else if (ob == best) { nbest += on; first = of < first ? of : first; }
+    }
+    const int only_pair = first >> 1, only_o = first & 1;
     // The divergent case analysis below only picks the parameters of the ONE record this read emits; the record
     // itself is built once, after the lanes have converged again (emit_op is by far the longest piece of code here).
     bool has_v = true;
     int pair = only_pair, o = only_o, sample = -1, rtype = SMX_R_UNKNOWN, barcode = -1, pool = -2;   // pool -2: the pair's
+    const bool lead = sub == 0;   // the lane that analyses the winner and emits; its partners only take part in the shuffles
     unsigned xflags = 0;
     int more1 = -1, more2 = -1, more3 = -1;   // further specimens of a tied full match
     if (best == 0) {   // no candidate at all (demultiplex.py:202-210)
@@ -744,17 +756,23 @@ __device__ inline bool score_fast(Emitter &E, int ori) {
         // several primer-only candidates (typically both orientations of one pair): no barcode logic involved.
         // dereplicate=best -> dereplicate_unknown_matches: stable minimum of (-primer_count, primer_dist, file index);
         // dereplicate=none -> every best candidate is written as UNKNOWN (demultiplex.py:181-197, :480-538): general path
-        if (P->derep == SMX_DEREP_NONE) return false;
-        int wkey = 0x7FFFFFFF;
-        for (int pr = 0; pr < P->NPAIR; pr++)
-            for (int oo = 0; oo < 2; oo++) {
-                if ((oo == 0 && ori == 2) || (oo == 1 && ori == 1)) continue;
-                CandView v = cand_view(c, pr, oo);
-                if (cand_score(v) != best) continue;
-                int k = key_unknown(c.LP, v);
-                if (k < wkey) { wkey = k; pair = pr; o = oo; }
-            }
+        if (P->derep == SMX_DEREP_NONE) return sub != 0;
+        int wkey = 0x7FFFFFFF, wci = 0x7FFF;
+        for (int ci = sub; ci < ncand; ci += G) {
+            const int pr = ci >> 1, oo = ci & 1;
+            if ((oo == 0 && ori == 2) || (oo == 1 && ori == 1)) continue;
+            CandView v = cand_view(c, pr, oo);
+            if (cand_score(v) != best) continue;
+            int k = key_unknown(c.LP, v);
+            if (k < wkey) { wkey = k; wci = ci; }   // first minimum in candidate order within this lane's stride
+        }
+        for (int d = 1; d < G; d <<= 1) {
+            const int ok = __shfl_xor(wkey, d, 64), oc = __shfl_xor(wci, d, 64);
+            if (ok < wkey || (ok == wkey && oc < wci)) { wkey = ok; wci = oc; }
+        }
+        pair = wci >> 1; o = wci & 1;
     } else {
+        if (!lead) return true;
         if (nbest != 1) return false;
         const CandView v = cand_view(c, pair, o);
         const HitL &a = c.hits[v.h1], &b = c.hits[v.h2];
@@ -804,6 +822,7 @@ __device__ inline bool score_fast(Emitter &E, int ori) {
             }
         }
     }
+    if (!lead) return true;
     if (pool == -2) pool = c.LP.pair_pool[pair];
     const CandView v = cand_view(c, pair, o);
     emit_op(E, has_v ? &v : nullptr, pair * 2 + o, sample, rtype, pool, barcode, xflags);
@@ -1218,9 +1237,6 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 if (rflagC[divH(item)] == 0) primer_item(item, true);
                 else fbq[atomicAdd(&aggr[10], 1)] = (unsigned short)item;
             }
-#if defined(SMX_EXP) && SMX_EXP == 10
-            STAMP(3);   // timing experiment: wave 0's own pass-1 time lands in the "entries" slot
-#endif
             __syncthreads();
             const int nfb = aggr[10];
             if (nfb > 0) {   // uniform; usually nothing was queued and the tile goes straight on
@@ -1639,18 +1655,22 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         if (have && wave < SW) {
             unsigned long long t_sc0 = 0;
             if (timing) t_sc0 = clock64();   // diagnostic: the scorer wave's own time inside the shared region
-            int r = tid;
+            // G lanes per read while the tile is smaller than the wave (R <= 32: panels with many primers)
+            const int lG = R <= 16 ? 2 : (R <= 32 ? 1 : 0), G = 1 << lG;
+            const int r = tid >> lG, sub = tid & (G - 1);
             if (r < nr) {
                 int L = lensC[r];
                 bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
-                atomicAdd(&aggr[0], 1);
+                if (sub == 0) atomicAdd(&aggr[0], 1);
                 if (filtered) {
-                    atomicAdd(&aggr[2], 1);
-                    smx_op op;
-                    op.sample = -1; op.trim_start = 0; op.trim_end = 0; op.pool = -1; op.p1 = op.p2 = -1; op.barcode = -1;
-                    op.dist[0] = op.dist[1] = op.dist[2] = op.dist[3] = -1;
-                    op.rtype = SMX_R_FILTERED; op.flags = 0; op.n_ops = 0; op.read = r0 + r;
-                    opsL[r] = op;
+                    if (sub == 0) {
+                        atomicAdd(&aggr[2], 1);
+                        smx_op op;
+                        op.sample = -1; op.trim_start = 0; op.trim_end = 0; op.pool = -1; op.p1 = op.p2 = -1; op.barcode = -1;
+                        op.dist[0] = op.dist[1] = op.dist[2] = op.dist[3] = -1;
+                        op.rtype = SMX_R_FILTERED; op.flags = 0; op.n_ops = 0; op.read = r0 + r;
+                        opsL[r] = op;
+                    }
                 } else {
                     ReadCtx c;
                     c.P = P; c.LP = LP; c.hits = hits + r * H; c.tiem = tiem + r * H * MBW; c.MBW = MBW; c.L = L; c.S = S;
@@ -1663,13 +1683,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     E.n_extra = tile_counter + 3;   // see the kernel's epilogue
                     E.counts = counts; E.emitlog = emitlog + r * SMX_MAX_EMIT; E.aggr = aggr; E.read = r0 + r;
                     E.n = 0; E.matched = false; E.overflow = false;
-                    if (score_fast(E, ori)) {
-                        opsL[r].n_ops = (uint16_t)E.n;
-                        if (E.matched) atomicAdd(&aggr[1], 1);
-                        if (E.n > 1) atomicAdd(&aggr[6], 1);
-                        if (E.overflow) atomicAdd(&aggr[7], 1);
-                    } else {
-                        score_general(E, ori);
+                    const bool done = score_fast(E, ori, sub, G);
+                    if (sub == 0) {
+                        if (!done) score_general(E, ori);
                         opsL[r].n_ops = (uint16_t)E.n;
                         if (E.matched) atomicAdd(&aggr[1], 1);
                         if (E.n > 1) atomicAdd(&aggr[6], 1);

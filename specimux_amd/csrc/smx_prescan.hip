@@ -88,11 +88,7 @@ __global__ __launch_bounds__(256) void prescan_transpose_kernel(int S, const uin
         for (int b2 = tid; b2 < PRE_G * ppr; b2 += NT) {   // b2 = c * 32 + g: 32 consecutive lanes store 32 consecutive groups
             const int c = b2 >> 5, g = b2 & 31;
             unsigned o[32];
-#if defined(SMX_EXP) && SMX_EXP == 11
-            for (int d = 0; d < 32; d++) o[d] = planes[(g * ppr + c) * PRE_BLK + d];   // timing experiment: no transpose (wrong planes, valid memory)
-#else
             prescan_transpose_block(planes, g * ppr + c, c, CH, o);
-#endif
             const int chunk = prescan_block_chunk(c, CH), lane = prescan_block_lane(g, c, CH);
 #pragma unroll
             for (int q = 0; q < 8; q++)

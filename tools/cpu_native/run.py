@@ -16,7 +16,7 @@ from specimux_amd import synth  # noqa: E402  (workload generator only)
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 765000
 tmp = tempfile.mkdtemp(prefix="smx_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-exe = os.path.join(tmp, "cpu_scan")
+exe = os.path.join(tempfile.mkdtemp(prefix="smx_cpu_exe_"), "cpu_scan")   # /dev/shm may be mounted noexec
 subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", os.path.join(REPO, "tools", "cpu_native", "cpu_scan.c"), "-o", exe])
 pan = synth.panel_c2(2002)
 rs = synth.make_reads(pan, n, 2002, workers=8)

@@ -30,7 +30,8 @@ def main():
     from specimux_amd import synth
     flag_sets = [dict(), dict(trim="tails"), dict(trim="primers"), dict(dereplicate="none"), dict(disable_prefilter=True),
                  dict(disable_preorient=True), dict(search_len=64), dict(search_len=120), dict(index_edit_distance=2),
-                 dict(primer_edit_distance=4), dict(index_edit_distance=4, disable_prefilter=True)]
+                 dict(primer_edit_distance=4), dict(index_edit_distance=4, disable_prefilter=True),
+                 dict(search_len=160, error_rate=0.12, n_frac=0.05), dict(search_len=48, n_frac=0.1), dict(search_len=96, trim="tails")]
     if a.trim:
         flag_sets = [dict(f, trim=a.trim) for f in flag_sets if "trim" not in f]
     if a.index_k is not None:
@@ -47,8 +48,10 @@ def main():
     for seed, (fi, flags) in itertools.product(range(a.seeds), enumerate(flag_sets)):
         name = ("c2", "c3", "c1")[(seed + fi) % 3]
         pan, (pf, sf) = panels[name], files[name]
+        flags = dict(flags)
+        gen = {k: flags.pop(k) for k in ("error_rate", "n_frac") if k in flags}   # generator-only knobs
         S = flags.get("search_len", 80)
-        rs = synth.make_reads(pan, a.reads, 9000 + 131 * seed + fi, search_len=S, windows_only=False)
+        rs = synth.make_reads(pan, a.reads, 9000 + 131 * seed + fi, search_len=S, windows_only=False, **gen)
         reads = reads_of(rs, a.reads, S)
         both = Both(pf, sf, **flags)
         both.assert_hits_equal(reads[:100], f"{name} seed {seed} {flags}")

@@ -143,6 +143,13 @@ struct smx_panel {
     size_t pre_lds = 0;                      // transpose kernel staging
     DevBuf pre_planes[SMX_MAX_STREAMS];      // per stream slot: the 2-bit text planes of the batch (read-tile major)
     DevBuf pre_recs[SMX_MAX_STREAMS];
+    DevBuf pre_match[SMX_MAX_STREAMS];       // per stream slot: match words [tile][2 * NP][32 groups] (bit = read reaches the threshold)
+    // compact mode of the lean kernel (panels with many primers): tiles of Rc reads that keep per-alignment records only
+    // for the nitems alignments the match words flag; a tile that needs more goes on the overflow list and is redone by a
+    // dense launch (R, lds) right behind the compact one.  nitems == 0: off.
+    int Rc = 0, nitems = 0, blocks_per_cu_c = 1;
+    size_t lds_c = 0;
+    DevBuf ovf[SMX_MAX_STREAMS];             // per stream slot: overflow list, one entry per compact tile
     hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};   // smx_debug_kernel_times: start, after transpose, after DP, end
     bool kev_on = false, kev_pre = false;        // per stream slot: [2 * NP][search_len / 16][n_reads rounded up to a tile] flag words
     unsigned long long *d_phase = nullptr;   // SMX_PHASE_TIMING diagnostic
@@ -338,7 +345,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
         auto pick = [&](size_t bud, int *Rout, size_t *need_out) {
             for (int R = rmax; R >= 1; R >>= 1) {
                 size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, slots,
-                                                  h.bs_ok);
+                                                  h.bs_ok, 0);
                 if (need <= bud || R == 1) { *Rout = R; *need_out = need; return; }
             }
         };
@@ -351,6 +358,33 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
         else { P->R = three ? R3 : R4; P->lds = three ? n3 : n4; }
     }
     if (const char *e = getenv("SMX_LDS_PAD")) P->lds += (size_t)atol(e);   // tuning experiment: residency vs LDS size
+    // compact mode: worth it when the dense tile had to shrink (R * 2 NP records do not fit) and the prescan is there to say
+    // which alignments matter.  Largest tile (multiples of 8 reads) at four workgroups per CU, or a larger one at three if
+    // that keeps more reads in flight (8-primer panel: the kernel's time falls as a + b / reads in flight from R = 24 x 4 to
+    // R = 64 x 3).  SMX_COMPACT=0 turns it off, SMX_COMPACT_ITEMS / SMX_COMPACT_R are test / tuning hooks.
+    {
+        const char *ce = getenv("SMX_COMPACT");
+        int items = 256;
+        if (const char *e = getenv("SMX_COMPACT_ITEMS")) items = std::max(2 * NP, std::min(256, atoi(e)));
+        if (P->pre_ok && !(ce && atoi(ce) == 0) && (P->R < 64 || getenv("SMX_COMPACT_ITEMS"))) {
+            auto need_c = [&](int R) { return smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, 0, h.bs_ok, items); };
+            int best_R = 0, best_blocks = 0;
+            size_t best_need = 0;
+            for (int R = 64; R >= 8; R -= 8) {
+                const size_t need = need_c(R);
+                if (need > 160 * 1024 - 2048) continue;
+                const int blocks = (int)std::min<size_t>(4, (160 * 1024 - 1024) / (need + 512));
+                if (blocks < 3) continue;   // two workgroups per CU lose more to exposed latency than their larger tiles win back
+                                            // (measured: 8-primer panel, -l 160: R = 64 x 2 is 40 % slower than R = 40 x 3)
+                if (R * blocks > best_R * best_blocks) { best_R = R; best_blocks = blocks; best_need = need; }
+            }
+            if (const char *e = getenv("SMX_COMPACT_R")) { best_R = std::max(1, std::min(64, atoi(e))); best_need = need_c(best_R); best_blocks = 1; }
+            const int dense_blocks = (int)std::min<size_t>(4, (160 * 1024 - 1024) / (P->lds + 512));
+            if (best_R > 0 && (best_R * best_blocks > P->R * dense_blocks || getenv("SMX_COMPACT_ITEMS") || getenv("SMX_COMPACT_R"))) {
+                P->Rc = best_R; P->nitems = items; P->lds_c = best_need;
+            }
+        }
+    }
     if (P->lds > 160 * 1024 || P->lds_slots > 160 * 1024) {
         const size_t need = std::max(P->lds, P->lds_slots);
         delete P;
@@ -399,6 +433,8 @@ void smx_panel_destroy(smx_panel *P) {
     if (P->d_tile_counter) (void)hipFree(P->d_tile_counter);
     for (auto &b : P->ws) b.release();
     for (auto &b : P->pre_recs) b.release();
+    for (auto &b : P->pre_match) b.release();
+    for (auto &b : P->ovf) b.release();
     for (auto &b : P->pre_planes) b.release();
     for (auto &e : P->kev) if (e) (void)hipEventDestroy(e);
     delete P;
@@ -457,9 +493,10 @@ static int ensure_device(smx_panel *P) {
     h.spec_p1m = (const unsigned long long *)(b + P->o_p1m); h.spec_p2m = (const unsigned long long *)(b + P->o_p2m);
     h.spec_pool = (const int *)(b + P->o_spec_pool);
     h.bs_re = (const unsigned *)(b + P->o_bsre);
-    if (std::max(P->lds, P->lds_slots) > 64 * 1024) {
-        int rc = smx_set_demux_lds_limit(P->use64, std::max(P->lds, P->lds_slots));
-        if (rc != 0) return fail(SMX_ERR_DEVICE, "cannot raise the dynamic LDS limit to %zu bytes", std::max(P->lds, P->lds_slots));
+    if (std::max(std::max(P->lds, P->lds_slots), P->lds_c) > 64 * 1024) {
+        const size_t lim = std::max(std::max(P->lds, P->lds_slots), P->lds_c);
+        int rc = smx_set_demux_lds_limit(P->use64, lim);
+        if (rc != 0) return fail(SMX_ERR_DEVICE, "cannot raise the dynamic LDS limit to %zu bytes", lim);
     }
     // persistent grid = exactly the resident workgroups (tiles are pulled from a queue): a workgroup that starts
     // after the queue has drained would only pay the panel staging and its one-time register spills
@@ -471,6 +508,11 @@ static int ensure_device(smx_panel *P) {
         occ = 0;
         if (smx_query_occupancy(P->use64, 0, P->lds_slots, &occ) != 0 || occ < 1) occ = 4;
         P->blocks_per_cu_slots = occ;
+        if (P->nitems > 0) {
+            occ = 0;
+            if (smx_query_occupancy_compact(bsv, P->lds_c, &occ) != 0 || occ < 1) occ = 4;
+            P->blocks_per_cu_c = occ;
+        }
     }
     if (P->pre_ok) {
         if (P->pre_lds > 64 * 1024 && smx_prescan_set_lds_limit(P->pre_lds) != 0)
@@ -481,15 +523,18 @@ static int ensure_device(smx_panel *P) {
         P->pre_blocks_d = occ_d;
         if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] prescan: transpose %d workgroups/CU (lds %zu), DP %d waves/CU\n", occ_t, P->pre_lds, occ_d);
     }
-    if (const char *e = getenv("SMX_BLOCKS_PER_CU")) P->blocks_per_cu = P->blocks_per_cu_slots = std::max(1, atoi(e));
+    if (const char *e = getenv("SMX_BLOCKS_PER_CU")) P->blocks_per_cu = P->blocks_per_cu_slots = P->blocks_per_cu_c = std::max(1, atoi(e));
     if (getenv("SMX_DEBUG")) {
         int occ = -1;
         (void)smx_query_occupancy(P->use64, !P->hp.bs_ok ? 0 : (P->hp.kidx < 4 ? 1 : 2), P->lds, &occ);
         fprintf(stderr, "[smx] lean R=%d lds=%zu | slots R=%d lds=%zu | occupancy API (lean): %d blocks/CU, grid multiplier %d, CUs %d\n",
                 P->R, P->lds, P->R_slots, P->lds_slots, occ, P->blocks_per_cu, P->n_cu);
+        if (P->nitems > 0)
+            fprintf(stderr, "[smx] compact lean tiles: R=%d, %d records, lds=%zu, %d blocks/CU (overflow tiles redone dense)\n", P->Rc,
+                    P->nitems, P->lds_c, P->blocks_per_cu_c);
     }
     if (getenv("SMX_PHASE_TIMING")) {
-        P->phase_grid = P->n_cu * std::max(P->blocks_per_cu, P->blocks_per_cu_slots);
+        P->phase_grid = P->n_cu * std::max(std::max(P->blocks_per_cu, P->blocks_per_cu_slots), P->blocks_per_cu_c);
         HIP_TRY(hipMalloc((void **)&P->d_phase, (size_t)P->phase_grid * 16 * 8));
         HIP_TRY(hipMemset(P->d_phase, 0, (size_t)P->phase_grid * 16 * 8));
         h.dbg_phase = P->d_phase;
@@ -517,6 +562,7 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     // see the hit table of the kernel that is benchmarked; its tail_end is defined only where that kernel computes it.
     const bool lean_tails = P->hp.bs_ok && P->hp.kidx < 4 && P->hp.maxB <= 32 && !getenv("SMX_NO_LEAN_TAILS");
     const int use_slots = ((P->hp.trim == SMX_TRIM_TAILS && !lean_tails) || d_bdist || getenv("SMX_FORCE_SLOTS")) ? 1 : 0;
+    const bool compact = !use_slots && P->nitems > 0 && P->pre_ok;
     const int R = use_slots ? P->R_slots : P->R;
     const size_t lds = use_slots ? P->lds_slots : P->lds;
     unsigned *tc = nullptr;
@@ -537,27 +583,47 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     if (P->pre_ok) {
         npad = (n_reads + smx::PRE_TILE - 1) / smx::PRE_TILE * smx::PRE_TILE;
         const size_t need = (size_t)2 * P->hp.NP * (P->hp.S >> 4) * npad * sizeof(unsigned);
-        DevBuf &pb = P->pre_recs[slot], &pp = P->pre_planes[slot];
+        DevBuf &pb = P->pre_recs[slot], &pp = P->pre_planes[slot], &pm = P->pre_match[slot], &ov = P->ovf[slot];
         const size_t need_planes = (size_t)(npad / smx::PRE_TILE) * (P->hp.S >> 4) * 8 * 64 * 4 * sizeof(unsigned);
-        if (need > pb.cap || need_planes > pp.cap) {
+        const size_t need_match = (size_t)(npad / smx::PRE_TILE) * 2 * P->hp.NP * smx::PRE_G * sizeof(unsigned);
+        const size_t need_ovf = compact ? ((size_t)n_reads / P->Rc + 2) * sizeof(unsigned) : 0;
+        if (need > pb.cap || need_planes > pp.cap || need_match > pm.cap || need_ovf > ov.cap) {
             if (pb.p || pp.p) (void)hipStreamSynchronize((hipStream_t)stream);   // earlier launches on this stream still use them
             hipError_t pe = pb.ensure(need);
             if (pe == hipSuccess) pe = pp.ensure(need_planes);
+            if (pe == hipSuccess) pe = pm.ensure(need_match);
+            if (pe == hipSuccess && need_ovf) pe = ov.ensure(need_ovf);
             if (pe != hipSuccess) return fail(SMX_ERR_DEVICE, "prescan buffers: %s", hipGetErrorString(pe));
         }
         const uint32_t ptiles = npad / smx::PRE_TILE;
         const int grid_t = (int)std::min<uint32_t>(ptiles, (uint32_t)(P->n_cu * P->pre_blocks_t));
         const int grid_d = (int)std::min<uint32_t>(ptiles * (uint32_t)P->hp.NP, (uint32_t)(P->n_cu * P->pre_blocks_d));
         int pe = smx_launch_prescan(&P->pre, P->pre_mr, P->pre_nx, grid_t, P->pre_lds, grid_d, stream, d_windows, d_lens, n_reads,
-                                    P->hp.wstride, (unsigned *)pp.p, (unsigned *)pb.p, P->kev_on ? (void *)P->kev[1] : nullptr);
+                                    P->hp.wstride, (unsigned *)pp.p, (unsigned *)pb.p, (unsigned *)pm.p,
+                                    P->kev_on ? (void *)P->kev[1] : nullptr);
         if (pe != 0) return fail(SMX_ERR_DEVICE, "prescan kernel launch failed: %s", hipGetErrorString((hipError_t)pe));
         d_pre = (const unsigned *)pb.p;
         if (P->kev_on) (void)hipEventRecord(P->kev[2], (hipStream_t)stream);
     }
     uint32_t tiles = (n_reads + R - 1) / R;
     int grid = (int)std::min<uint32_t>(tiles, (uint32_t)(P->n_cu * (use_slots ? P->blocks_per_cu_slots : P->blocks_per_cu)));
-    int e = smx_launch_demux(&P->hp, P->use64, R, grid, lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
-                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, use_slots, d_pre, npad);
+    int e;
+    if (compact) {
+        // compact launch over all reads, then the dense launch over the reads of the tiles it put on the overflow list
+        // (usually none: its workgroups find an empty list and leave)
+        smx::DemuxAux ax = {(const unsigned *)P->pre_match[slot].p, (unsigned *)P->ovf[slot].p, P->nitems, 0, P->Rc, 1};
+        const uint32_t ctiles = (n_reads + P->Rc - 1) / P->Rc;
+        const int cgrid = (int)std::min<uint32_t>(ctiles, (uint32_t)(P->n_cu * P->blocks_per_cu_c));
+        e = smx_launch_demux(&P->hp, P->use64, P->Rc, cgrid, P->lds_c, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
+                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, 0, d_pre, npad, &ax);
+        if (e == 0) {
+            smx::DemuxAux rx = {nullptr, (unsigned *)P->ovf[slot].p, 0, 1, P->Rc, 0};
+            e = smx_launch_demux(&P->hp, P->use64, R, grid, lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
+                                 extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, 0, d_pre, npad, &rx);
+        }
+    } else
+        e = smx_launch_demux(&P->hp, P->use64, R, grid, lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
+                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, use_slots, d_pre, npad, nullptr);
     if (e != 0) return fail(SMX_ERR_DEVICE, "demux kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     if (P->kev_on) (void)hipEventRecord(P->kev[3], (hipStream_t)stream);
     return SMX_OK;

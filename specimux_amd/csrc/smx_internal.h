@@ -44,24 +44,35 @@ struct DevPanel {
     unsigned long long *dbg_phase;        // SMX_PHASE_TIMING=1: [grid][16] cycle sums per phase (diagnostic build-in)
 };
 
+// Compact mode and the redo launch behind it (smx_kernels.hip, demux_kernel).
+struct DemuxAux {
+    const unsigned *match;   // prescan match words [tile of 1024 reads][alignment][32-read group]; compact mode only
+    unsigned *ovf_list;      // compact launch: the tiles it could not hold (appended); redo launch: the tiles to process
+    int nitems;              // > 0: compact mode, this many per-alignment records per tile (<= 256)
+    int redo;                // 1: this launch processes the reads of ovf_list's tiles (Rc reads each) and nothing else
+    int Rc;                  // reads per tile of the compact launch
+    int chain;               // 1: another launch of this batch follows: the extra-record and overflow counters stay
+};
+
 }  // namespace smx
 
 extern "C" {
 int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t lds_bytes, void *stream,
                      const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops, smx_op *d_extra,
                      uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts, smx_hit *d_hits, int8_t *d_bdist,
-                     unsigned *d_tile_counter, int use_slots, const unsigned *d_pre, uint32_t npad);
+                     unsigned *d_tile_counter, int use_slots, const unsigned *d_pre, uint32_t npad, const smx::DemuxAux *aux);
 // primer prescan (smx_prescan.hip)
 size_t smx_prescan_lds_bytes(int S);
 int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int grid_t, size_t lds_t, int grid_d, void *stream,
                        const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride, unsigned *d_planes,
-                       unsigned *d_out, void *ev_mid);
+                       unsigned *d_out, unsigned *d_match, void *ev_mid);
 int smx_prescan_set_lds_limit(size_t bytes);
 int smx_prescan_occupancy(int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d);
 size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta, int kidx,
-                           int slots, int bs);
+                           int slots, int bs, int nitems);
 int smx_set_demux_lds_limit(int use64, size_t bytes);
 int smx_query_occupancy(int use64, int bsv, size_t lds_bytes, int *blocks_per_cu);
+int smx_query_occupancy_compact(int bsv, size_t lds_bytes, int *blocks_per_cu);
 int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,
                      const unsigned char *d_tcodes, int n, int k, int mode, int *d_dist, unsigned char *d_endflag,
                      int *d_starts);

@@ -121,7 +121,8 @@ static_assert(sizeof(HitL) == 16, "HitL layout");
 #define SMX_MAX_EMIT 16
 struct TileLayout {   // byte offsets into dynamic LDS
     int tacc, ppeq, prpeq, bpeq, bsre, lut, pmeta, codes, namask, lens, ocnt, rflag, hits, masks, tiem, bres, dmask, ents, offsA, offsB, queue, emit, opsL, aggr, etail,
-        total;
+        hmap, clist, pmask, hcand, total;
+    int NI;      // per-alignment records a tile keeps: R * H (dense) or the compact capacity
     int CS;      // bytes per code row (odd number of dwords: conflict-free column reads across rows)
     int lNPs, lNBs;  // their log2
     int NPs, NBs;  // power-of-two strides of the transposed Peq tables: entry [code][pattern]
@@ -146,7 +147,10 @@ static_assert(sizeof(EntL) == 12, "EntL layout");
 template <typename PW>
 __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, int maxB, int need_starts,
                                                     int npmeta, int kidx, int slots, int bs, int cap_hits = 0,
-                                                    int cap_ents = 0) {
+                                                    int cap_ents = 0, int nitems = 0) {
+    // nitems > 0: compact mode.  The tile keeps per-alignment state (hit record, end mask, scan slots) for at most nitems
+    // of its R * H alignments -- the ones the prescan's match words flag -- plus one shared "no match" record; hmap maps
+    // (read, alignment) to its record.  Panels with many primers spend most of their LDS on alignments that never match.
     TileLayout t;
     int H = 2 * NP, MW = (S + 31) / 32;
     t.CS = 4 * (((S + 3) / 4) | 1);
@@ -158,10 +162,15 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     // barcode rounds.  slots mode (--trim tails, parity dumps): one 4-byte atomicMin slot per (hit, barcode),
     // at most 16 KiB worth of hits per round.  lean mode: per hit only (k+1) x MBW words of "barcodes seen at
     // distance d" bitmasks, at most 4 KiB per round.
-    int dense = R * H;
-    int fit = slots ? (16 * 1024) / (t.G * 4) : (3 * 1024) / ((kidx + 1) * t.MBW * 4);
+    const int sentinel = nitems > 0 ? 1 : 0;
+    t.NI = nitems > 0 ? nitems : R * H;
+    int dense = t.NI;
+    // (compact mode: up to 8 KiB, so that the searched hits of a 64-read tile usually go in ONE round -- the several-round
+    // path has serial bookkeeping)
+    int fit = slots ? (16 * 1024) / (t.G * 4) : ((nitems > 0 ? 8 : 3) * 1024) / ((kidx + 1) * t.MBW * 4);
     t.CAPH = dense < fit ? dense : (fit < 1 ? 1 : fit);
     t.CAPE = t.CAPH + t.CAPH / 4 < 256 ? 256 : t.CAPH + t.CAPH / 4;   // >= 256 = max locations of one hit (progress)
+    if (nitems > 0) t.CAPE = 2 * t.CAPH < 256 ? 256 : 2 * t.CAPH;     // (noisy reads of a wide window: two optimal ends per hit)
     if (cap_hits > 0 && cap_hits < t.CAPH) t.CAPH = cap_hits;          // test hook: many small rounds
     if (cap_ents >= S && cap_ents < t.CAPE) t.CAPE = cap_ents;         // (a hit has at most S locations)
     int o = 0;
@@ -179,8 +188,10 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.lens = o;  o += 2 * R * 4;               // double-buffered: the next tile is encoded while this one is scored
     t.ocnt = o;  o += 2 * R * 4;               // per read: forward votes | reverse votes << 16; double-buffered
     t.rflag = o; o += 2 * R * 4;               // per read: 1 = a window holds something other than upper-case ACGT: scalar primer scan; double-buffered
-    t.hits = o;  o += R * H * (int)sizeof(HitL);
-    t.tiem = o;  o += R * H * t.MBW * 4;
+    t.hits = o;  o += (t.NI + sentinel) * (int)sizeof(HitL);
+    t.tiem = o;  o += (t.NI + sentinel) * t.MBW * 4;
+    t.hmap = o;  o += nitems > 0 ? ((R * H + 1) & ~1) * 2 : 0;     // (read, alignment) -> record; t.NI = the shared "no match" record
+    t.clist = o; o += nitems > 0 ? ((t.NI + 1) & ~1) * 2 : 0;       // record -> read * H + alignment
     // time-shared regions: {location entries} are dead after the barcode scan -> staged result records;
     // {primer end masks, scans, queue} are dead once the scorer starts -> its emission log
     t.bres = t.dmask = o; o += slots ? t.CAPH * t.G * 4 : t.CAPH * (kidx + 1) * t.MBW * 4;
@@ -190,12 +201,15 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
         t.ents = t.opsL = o; o += c > d ? c : d;
     }
     t.etail = o; o += (bs && !slots) ? t.CAPE * 4 : 0;   // --trim tails on the lean path: end of the kept alignment per entry
-    t.masks = t.emit = o; o += R * H * MW * 4;
-    t.offsA = o; o += (R * H + 1) * 4;
-    t.offsB = o; o += (R * H + 1) * 4;
-    t.queue = o; o += ((R * H + 1) & ~1) * 2;
+    t.masks = t.emit = o; o += t.NI * MW * 4;
+    t.offsA = o; o += (t.NI + 1) * 4;
+    t.offsB = o; o += (t.NI + 1) * 4;
+    t.queue = o; o += ((t.NI + 1) & ~1) * 2;
     if (o < t.emit + R * SMX_MAX_EMIT * 4) o = t.emit + R * SMX_MAX_EMIT * 4;
     t.aggr = o;  o += 12 * 4;
+    o = (o + 7) & ~7;
+    t.pmask = o; o += R * 8;                   // per read: bit h = alignment h found its primer (scorer: which candidates to look at)
+    t.hcand = o; o += (H <= 64 ? H : 0) * 8;   // per alignment: the candidates (pair * 2 + orientation) it belongs to
     t.total = (o + 15) & ~15;
     return t;
 }
@@ -489,9 +503,14 @@ struct LPanel {
 struct ReadCtx {
     const DevPanel *P;
     LPanel LP;
-    const HitL *hits;          // this read's H records
-    const unsigned *tiem;      // this read's H*MBW tie bitmasks (barcodes at the best distance)
+    const HitL *hits;          // this read's H records (compact mode: the tile's records, indexed through hmap)
+    const unsigned *tiem;      // the records' MBW tie bitmasks each (barcodes at the best distance)
+    const unsigned short *hmap;   // compact mode: this read's alignment -> record; nullptr: record = alignment
+    const unsigned long long *hcand;   // per alignment: bitmask of the candidates it belongs to; nullptr: look at every candidate
+    unsigned long long pm;        // this read's alignments with a primer match (bit h)
     int MBW;
+    __device__ __forceinline__ int rec(int h) const { return hmap ? (int)hmap[h] : h; }
+    __device__ __forceinline__ const HitL &hit(int h) const { return hits[rec(h)]; }
     int L, S;
     EndGeom g;
 };
@@ -510,8 +529,8 @@ __device__ __forceinline__ CandView cand_view(const ReadCtx &c, int pair, int o)
     v.o = o;
     v.h1 = v.f * 2 + (o == 0 ? 0 : 1);   // forward primer: end A (of rs) when the read is kept as is
     v.h2 = v.r * 2 + (o == 0 ? 1 : 0);
-    const HitL &a = c.hits[v.h1];
-    const HitL &b = c.hits[v.h2];
+    const HitL &a = c.hit(v.h1);
+    const HitL &b = c.hit(v.h2);
     v.p1 = a.pdist >= 0;
     v.p2 = b.pdist >= 0;
     v.b1 = v.p1 && a.bbest >= 0;
@@ -536,7 +555,7 @@ __device__ __forceinline__ int cand_score(const CandView &v) {   // demultiplex.
 __device__ inline int next_tied(const ReadCtx &c, int h, int from) {
     int p = h >> 1;
     int nb = c.LP.pbc_off[p + 1] - c.LP.pbc_off[p];
-    const unsigned *tm = c.tiem + h * c.MBW;
+    const unsigned *tm = c.tiem + c.rec(h) * c.MBW;
     for (int i = from; i < nb; i++)
         if ((tm[i >> 5] >> (i & 31)) & 1) return i;
     return -1;
@@ -562,8 +581,8 @@ __device__ inline int specimen_exact(const DevPanel *P, int gb1, int gb2, int f,
 __device__ inline void cand_extent(const ReadCtx &c, const CandView &v, int cum, int &s, int &e) {
     const DevPanel *P = c.P;
     int L = c.L;
-    const HitL &a = c.hits[v.h1];
-    const HitL &b = c.hits[v.h2];
+    const HitL &a = c.hit(v.h1);
+    const HitL &b = c.hit(v.h2);
     // first primer location in reference coordinates of the searched string
     int a_end = 0, a_start = 0, b_end = 0, b_start = 0;
     if (v.p1) { a_end = (int)a.jstar - c.g.j_lo + c.g.shift; a_start = (int)a.fs_j - c.g.j_lo + c.g.shift; }
@@ -666,10 +685,10 @@ __device__ inline void emit_op(Emitter &E, const CandView *v, int cand_id, int s
 // resolve_specimen for a non-full candidate (demultiplex.py:576-589) -> emits.
 __device__ inline void emit_partial_or_unknown(Emitter &E, const CandView &v, int cand_id, int pool) {
     const ReadCtx &c = *E.c;
-    if (v.b1 && !v.b2 && c.hits[v.h1].ntied == 1)
-        emit_op(E, &v, cand_id, -1, SMX_R_PARTIAL_FWD, pool, global_bc(c, v.h1, c.hits[v.h1].first_tied), 0);
-    else if (v.b2 && !v.b1 && c.hits[v.h2].ntied == 1)
-        emit_op(E, &v, cand_id, -1, SMX_R_PARTIAL_REV, pool, global_bc(c, v.h2, c.hits[v.h2].first_tied), 0);
+    if (v.b1 && !v.b2 && c.hit(v.h1).ntied == 1)
+        emit_op(E, &v, cand_id, -1, SMX_R_PARTIAL_FWD, pool, global_bc(c, v.h1, c.hit(v.h1).first_tied), 0);
+    else if (v.b2 && !v.b1 && c.hit(v.h2).ntied == 1)
+        emit_op(E, &v, cand_id, -1, SMX_R_PARTIAL_REV, pool, global_bc(c, v.h2, c.hit(v.h2).first_tied), 0);
     else
         emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, pool, -1, 0);
 }
@@ -729,6 +748,26 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
     // ---- select_best_matches (demultiplex.py:216-259): best score, how many carry it, the first of them
     int best = 0, nbest = 0, first = 0x7FFF;
     const int ncand = P->NPAIR * 2;
+    // Panels with many primer pairs: a candidate scores > 0 only if one of its two alignments found its primer, so only the
+    // candidates of this read's matched alignments are looked at (a handful of the 2 * NPAIR); nothing else changes --
+    // best / nbest / first are functions of the candidates with a positive score.
+    unsigned long long live = ~0ull;
+    if (c.hcand) {
+        live = 0ull;
+        for (unsigned long long m = c.pm; m; m &= m - 1ull) live |= c.hcand[__ffsll((long long)m) - 1];
+        if (ori == 2) live &= 0xAAAAAAAAAAAAAAAAull;        // reverse-complement candidates only (odd ids)
+        else if (ori == 1) live &= 0x5555555555555555ull;
+    }
+    if (c.hcand) {
+        for (unsigned long long m = live; m; m &= m - 1ull) {
+            const int ci = __ffsll((long long)m) - 1;
+            if ((ci & (G - 1)) != sub) continue;
+            CandView v = cand_view(c, ci >> 1, ci & 1);
+            int sc = cand_score(v);
+            if (sc > best) { best = sc; nbest = 1; first = ci; }
+            else if (sc == best) { nbest++; first = ci < first ? ci : first; }
+        }
+    } else
     for (int ci = sub; ci < ncand; ci += G) {
         const int pair = ci >> 1, o = ci & 1;
         if ((o == 0 && ori == 2) || (o == 1 && ori == 1)) continue;
@@ -761,6 +800,7 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
         for (int ci = sub; ci < ncand; ci += G) {
             const int pr = ci >> 1, oo = ci & 1;
             if ((oo == 0 && ori == 2) || (oo == 1 && ori == 1)) continue;
+            if (!((live >> ci) & 1ull)) continue;
             CandView v = cand_view(c, pr, oo);
             if (cand_score(v) != best) continue;
             int k = key_unknown(c.LP, v);
@@ -775,7 +815,7 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
         if (!lead) return true;
         if (nbest != 1) return false;
         const CandView v = cand_view(c, pair, o);
-        const HitL &a = c.hits[v.h1], &b = c.hits[v.h2];
+        const HitL &a = c.hit(v.h1), &b = c.hit(v.h2);
         const bool t1 = !v.b1 || a.ntied == 1, t2 = !v.b2 || b.ntied == 1;
         if (best <= 2) {
             // dereplicate_unknown_matches / resolve_specimen: UNKNOWN either way
@@ -964,14 +1004,15 @@ __device__ inline void score_general(Emitter &E, int ori) {
 // BSV selects the barcode scan compiled into the kernel (one variant per kernel keeps their register allocations
 // apart): 0 = per-barcode bit-vector scan only, 1 = bit-sliced, k <= 3 (padded 7-row window), 2 = bit-sliced, k 4..7,
 // 3 = variant 1 + the --trim tails extent on the lean path (<= 32 barcodes per primer).
-template <typename PW, int NT, int BSV>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
+// CM = 1: compact mode compiled in (its own instantiation: the dense kernel's register allocation stays as it was).
+template <typename PW, int NT, int BSV, int CM = 0>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
 __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
                                                     unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist,
                                                     unsigned *tile_counter, int use_slots,
-                                                    const unsigned *__restrict__ pre, uint32_t npad) {
+                                                    const unsigned *__restrict__ pre, uint32_t npad, DemuxAux aux) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
     const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
@@ -979,7 +1020,11 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
     const int use_bs = (BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0;
     const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta, P->kidx, use_slots, P->bs_ok,
-                                         P->cap_hits, P->cap_ents);
+                                         P->cap_hits, P->cap_ents, aux.nitems);
+    // compact mode (aux.nitems > 0, lean launches of many-primer panels behind the prescan): records only for the
+    // alignments the prescan's match words flag; a tile with more flagged alignments than records is put on the
+    // overflow list and left to the dense redo launch that follows (aux.redo)
+    constexpr bool cmode = CM != 0;
     PW *ppeq = (PW *)(lds + T.ppeq);        // [code][primer], stride NPs
     PW *prpeq = (PW *)(lds + T.prpeq);
     unsigned *bpeq = (unsigned *)(lds + T.bpeq);   // [code][barcode], stride NBs
@@ -1002,9 +1047,34 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     unsigned short *queue = (unsigned short *)(lds + T.queue);   // rank -> hit
     unsigned *emitlog = (unsigned *)(lds + T.emit);
     smx_op *opsL = (smx_op *)(lds + T.opsL);
-    int *aggr = (int *)(lds + T.aggr);      // [0..7] counters, [8] round end rank
+    int *aggr = (int *)(lds + T.aggr);      // [0..7] counters, [8] round end rank, [9] next tile, [10] fallback items, [11] flagged alignments
+    unsigned short *hmap = (unsigned short *)(lds + T.hmap);     // compact mode: read * H + alignment -> record (T.NI = "no match")
+    unsigned short *clist = (unsigned short *)(lds + T.clist);   // compact mode: record -> read * H + alignment
+    unsigned long long *pmask = (unsigned long long *)(lds + T.pmask);   // per read: alignments with a primer match
+    unsigned long long *hcand = (unsigned long long *)(lds + T.hcand);   // per alignment: its candidates
+    const bool cfilt = H <= 64 && P->NPAIR * 2 <= 64 && P->NPAIR * 2 > 4;   // the scorer looks at matched alignments' candidates only
     int tid = threadIdx.x;
     const int wave = tid >> 6;
+    // The launch counters re-arm themselves: tile_counter = {tile queue head, overflow tiles, finished workgroups, extra
+    // records}.  The last workgroup to get here zeroes the queue head; the last launch of a batch (aux.chain == 0) also
+    // publishes the extra-record count and zeroes the rest, so a launch needs no memset in front of it (two small fills
+    // per batch were ~2 % of a 0.4 ms launch).
+    auto workgroup_done = [&]() {
+        __threadfence();
+        const unsigned prev = atomicAdd(tile_counter + 2, 1u);
+        if (prev == gridDim.x - 1) {
+            __threadfence();
+            tile_counter[0] = 0; tile_counter[2] = 0;
+            if (!aux.chain) {
+                *n_extra = atomicAdd(tile_counter + 3, 0u);
+                tile_counter[1] = 0; tile_counter[3] = 0;
+            }
+        }
+    };
+    if (aux.redo && tile_counter[1] == 0) {   // the usual redo launch: nothing on the list (every workgroup sees the same count:
+        if (tid == 0) workgroup_done();       // it is only zeroed once all of them have passed this point)
+        return;
+    }
     constexpr int PWBITS = (int)sizeof(PW) * 8;
     const int CS = T.CS, NPs = T.NPs, NBs = T.NBs, lNPs = T.lNPs, lNBs = T.lNBs, G = T.G, logG = T.logG, MBW = T.MBW;
 
@@ -1041,6 +1111,23 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         }
     }
     if (tid < 12) aggr[tid] = 0;
+    for (int i = tid; i < R; i += NT) pmask[i] = 0ull;
+    if (cfilt) for (int i = tid; i < H; i += NT) hcand[i] = 0ull;
+    if (cmode && tid == 0) {   // the shared record of every alignment that is not flagged: what the primer scan writes for "no match"
+        HitL hn;
+        hn.tail_end = -1; hn.nloc = 0; hn.ntied = 0; hn.first_tied = -1; hn.pdist = -1; hn.bbest = -2; hn.jstar = 0; hn.fs_j = 0;
+        hn.flags = 0; hn.pad = 0;
+        hits[T.NI] = hn;
+        for (int w = 0; w < T.MBW; w++) tiem[T.NI * T.MBW + w] = 0;
+    }
+    __syncthreads();
+    if (cfilt)
+        for (int ci = tid; ci < P->NPAIR * 2; ci += NT) {   // candidate ci = (pair, orientation): its two alignments (cand_view)
+            const int pair = ci >> 1, o = ci & 1;
+            const int h1 = LP.pair_f[pair] * 2 + (o == 0 ? 0 : 1), h2 = LP.pair_r[pair] * 2 + (o == 0 ? 1 : 0);
+            atomicOr(&hcand[h1], 1ull << ci);
+            atomicOr(&hcand[h2], 1ull << ci);
+        }
     __syncthreads();
 
     const int stride = P->wstride;
@@ -1052,7 +1139,23 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     const unsigned Hmagic = (unsigned)((0x100000000ull + (unsigned)H - 1) / (unsigned)H);
     auto divH = [&](int x) -> int { return lH >= 0 ? (x >> lH) : (int)__umulhi((unsigned)x, Hmagic); };
     const unsigned hcmagic = (unsigned)((0x100000000ull + (unsigned)(S >> 4) - 1) / (unsigned)((S >> 4) > 0 ? (S >> 4) : 1));   // chunk / (S/16)
-    const uint32_t n_tiles = (n_reads + R - 1) / R;
+    // tile -> reads.  Normal launch: tile t = reads [t R, t R + R).  Redo launch: the overflow list holds tiles of Rc reads
+    // each; every one of them is cut into ceil(Rc / R) tiles of this launch.
+    const uint32_t redo_ratio = aux.redo ? (uint32_t)((aux.Rc + R - 1) / R) : 1u;
+    const uint32_t n_tiles = aux.redo ? tile_counter[1] * redo_ratio : (n_reads + R - 1) / R;
+    auto tile_span = [&](uint32_t t, uint32_t &first, int &count) {
+        if (!aux.redo) {
+            first = t * (uint32_t)R;
+            count = (int)((n_reads - first) < (uint32_t)R ? (n_reads - first) : (uint32_t)R);
+        } else {
+            const uint32_t seg = t / redo_ratio, sub = t - seg * redo_ratio;
+            const uint32_t base = aux.ovf_list[seg] * (uint32_t)aux.Rc;
+            const uint32_t end = base + (uint32_t)aux.Rc < n_reads ? base + (uint32_t)aux.Rc : n_reads;
+            first = base + sub * (uint32_t)R;
+            count = first < end ? (int)((end - first) < (uint32_t)R ? (end - first) : (uint32_t)R) : 0;
+            if (count == 0) first = base;   // keep addresses formed from it in range
+        }
+    };
     // diagnostic phase timing (SMX_PHASE_TIMING=1): thread 0 accumulates s_memtime deltas per phase, in LDS so that
     // the accumulators cost no registers in the production path
     unsigned long long *tacc = (unsigned long long *)(lds + T.tacc);   // [0..9] sums, [10] previous stamp
@@ -1078,9 +1181,12 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         // it the first barrier of every tile)
         unsigned popped = 0;
         if (tid == 0) popped = atomicAdd(tile_counter, 1u);
-        const uint32_t r0 = have ? cur * R : 0u;
-        const int nr = have ? (int)((n_reads - r0) < (uint32_t)R ? (n_reads - r0) : (uint32_t)R) : 0;
+        uint32_t r0 = 0u;
+        int nr = 0;
+        if (have) tile_span(cur, r0, nr);
         const int nh = nr * H;
+        int nI = nh;          // alignments with a record: all of them, or (compact mode) the flagged ones
+        bool live = have;     // false: nothing to do for `cur` (none yet, or a compact tile left to the redo launch)
         int *lensC = lensL + par * R, *ocntC = ocnt + par * R;
         const int *rflagC = rflag + par * R;
         if (timing) tacc[10] = clock64();
@@ -1090,8 +1196,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         // and scanned afterwards, packed into the lowest lanes, so that one such read does not make its whole wave run
         // the 80-column scalar scan.
         unsigned short *fbq = queue;   // fallback items (the rank -> hit queue is not live before phase 3a)
-        auto primer_item = [&](int item, const bool use_pre) {
-            int r = divH(item), h = item - __mul24(r, H), p = h >> 1, X = h & 1;
+        auto primer_item = [&](int item, const bool use_pre) {   // item = record index
+            const int dn = cmode ? (int)clist[item] : item;
+            int r = divH(dn), h = dn - __mul24(r, H), p = h >> 1, X = h & 1;
             int L = lensC[r];
             EndGeom g = end_geom(L, S);
             const unsigned char *cw = codes + __mul24(r * 2 + X, CS);
@@ -1225,6 +1332,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             hl.jstar = (unsigned char)jstar; hl.fs_j = (unsigned char)fs_j;
             hl.flags = (unsigned char)(omatch ? 1 : 0); hl.pad = 0;
             hits[item] = hl;
+            if (cfilt && matched) atomicOr(&pmask[r], 1ull << h);
             if (omatch) {
                 // determine_orientation via A.6: fwd primer in A / rev primer in B vote "forward"
                 int dir = LP.pdir[p];
@@ -1232,9 +1340,43 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 atomicAdd(&ocntC[r], vote_fwd ? 1 : 0x10000);
             }
         };
-        if (pre != nullptr) {
-            for (int item = tid; item < nh; item += NT) {
-                if (rflagC[divH(item)] == 0) primer_item(item, true);
+        if (cmode) {
+            // which alignments get a record: the ones the prescan flags, and every alignment of a read the prescan
+            // does not cover (rflag).  All match-word loads of a batch are issued before the first is used.
+            for (int i0 = tid; i0 < nh; i0 += 4 * NT) {
+                unsigned mw[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u * NT < nh ? i0 + u * NT : nh - 1;
+                    const int r = divH(i), h = i - __mul24(r, H);
+                    const uint32_t gr = r0 + (uint32_t)r;
+                    mw[u] = aux.match[((size_t)(gr >> 10) * H + h) * PRE_G + ((gr & (PRE_TILE - 1)) >> 5)] >> (gr & 31);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u * NT;
+                    if (i < nh) {
+                        const bool flagged = (mw[u] & 1u) || rflagC[divH(i)] != 0;
+                        int rec = T.NI;
+                        if (flagged) {
+                            const int sl = atomicAdd(&aggr[11], 1);
+                            if (sl < T.NI) { clist[sl] = (unsigned short)i; rec = sl; }
+                        }
+                        hmap[i] = (unsigned short)rec;
+                    }
+                }
+            }
+            __syncthreads();
+            nI = aggr[11];
+            if (nI > T.NI) {   // does not fit: the redo launch takes this tile's reads
+                live = false;
+                if (tid == 0) aux.ovf_list[atomicAdd(tile_counter + 1, 1u)] = cur;
+            }
+        }
+        if (!live) {
+        } else if (pre != nullptr) {
+            for (int item = tid; item < nI; item += NT) {
+                if (rflagC[divH(cmode ? (int)clist[item] : item)] == 0) primer_item(item, true);
                 else fbq[atomicAdd(&aggr[10], 1)] = (unsigned short)item;
             }
             __syncthreads();
@@ -1245,18 +1387,20 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 if (tid == 0) aggr[10] = 0;   // read by everyone before the barrier above; next written in the next tile's phase 2
             }
         } else {
-            for (int item = tid; item < nh; item += NT) primer_item(item, false);
+            for (int item = tid; item < nI; item += NT) primer_item(item, false);
             __syncthreads();
         }
         STAMP(1);
+        if (live) {
 
         // ---- phase 3a: orientation, which ends need barcodes; block-wide scans of locations and searched hits;
         //      one *entry* per optimal primer location of every searched hit
-        if (dbg_bdist)
+        if (dbg_bdist)   // (slots mode only: never compact)
             for (int i = tid; i < nh * maxB; i += NT) dbg_bdist[(size_t)r0 * H * maxB + i] = -1;
         // which ends need barcodes (find_candidate_matches:677-741) -> number of locations to search
         auto locations_needed = [&](int item) -> int {
-            int r = divH(item), h = item - __mul24(r, H), p = h >> 1, X = h & 1;
+            const int dn = cmode ? (int)clist[item] : item;
+            int r = divH(dn), h = dn - __mul24(r, H), p = h >> 1, X = h & 1;
             int L = lensC[r];
             int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
             int ori = 3;   // bit0: as-read candidates allowed, bit1: reverse-complement candidates allowed
@@ -1277,7 +1421,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         };
         // the optimal locations of one searched hit -> entries e, e+1, ... (target start, prefilter verdict)
         auto list_entries = [&](int item, int rank_in_round, int e) {
-            int r = divH(item), h = item - __mul24(r, H), X = h & 1;
+            const int dn = cmode ? (int)clist[item] : item;
+            int r = divH(dn), h = dn - __mul24(r, H), X = h & 1;
             const HitL &hl = hits[item];
             int L = lensC[r];
             EndGeom g = end_geom(L, S);
@@ -1317,9 +1462,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         };
         bool prelisted = false;   // the usual case: one item per lane and everything fits one round ->
         int nq = 0, nE_pre = 0;   // scans by shuffles, entries listed by the hit's own lane, three barriers fewer
-        if (nh <= NT) {
+        if (nI <= NT) {
             const int item = tid;
-            const int n = item < nh ? locations_needed(item) : 0;
+            const int n = item < nI ? locations_needed(item) : 0;
             const unsigned pk = (unsigned)n | ((n > 0 ? 1u : 0u) << 16);   // locations | searched hits << 16
             unsigned incl = pk;
             for (int d = 1; d < 64; d <<= 1) {
@@ -1347,27 +1492,27 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 __syncthreads();
             } else {   // several rounds: hand the scans over to the general code below
                 __syncthreads();   // wsum (in offsB) has been read by everyone
-                if (item < nh) {
+                if (item < nI) {
                     offsA[item] = (int)(excl & 0xFFFFu);
                     offsB[item] = (int)(excl >> 16);
                     if (n > 0) queue[excl >> 16] = (unsigned short)item;
                 }
-                if (tid == 0) { offsA[nh] = totE; offsB[nh] = nq; }
+                if (tid == 0) { offsA[nI] = totE; offsB[nI] = nq; }
                 __syncthreads();
             }
         } else {
-            for (int item = tid; item < nh; item += NT) {
+            for (int item = tid; item < nI; item += NT) {
                 int n = locations_needed(item);
                 offsA[item] = n;
                 offsB[item] = n > 0 ? 1 : 0;
             }
             __syncthreads();
-            if (wave == 0) wave_exclusive_scan(offsA, nh);
-            else if (wave == 1) wave_exclusive_scan(offsB, nh);
+            if (wave == 0) wave_exclusive_scan(offsA, nI);
+            else if (wave == 1) wave_exclusive_scan(offsB, nI);
             __syncthreads();
-            for (int item = tid; item < nh; item += NT)
+            for (int item = tid; item < nI; item += NT)
                 if (offsB[item + 1] != offsB[item]) queue[offsB[item]] = (unsigned short)item;
-            nq = offsB[nh];
+            nq = offsB[nI];
             __syncthreads();
         }
 #if defined(SMX_EXP) && SMX_EXP == 6
@@ -1381,21 +1526,20 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             if (prelisted) { q1 = nq; nE = nE_pre; }
             else {
                 e_base = offsA[queue[q0]];
-                if (nq - q0 <= T.CAPH && offsA[nh] - e_base <= T.CAPE) q1 = nq;   // everything left fits
+                if (nq - q0 <= T.CAPH && offsA[nI] - e_base <= T.CAPE) q1 = nq;   // everything left fits
                 else {
-                    if (tid == 0) {
-                        int q = q0 + 1;   // one hit always fits: CAPE >= 256 >= its locations
-                        while (q < nq && q - q0 < T.CAPH) {
-                            int hq = queue[q];
-                            if (offsA[hq] + hits[hq].nloc - e_base > T.CAPE) break;
-                            q++;
-                        }
-                        aggr[8] = q;
+                    // the round takes hits q0 .. q1 - 1: as many as fit both capacities.  "Hits q0 .. q - 1 fit" is monotone in
+                    // q, so every lane tests its own q and the largest one that passes wins.
+                    if (tid == 0) aggr[8] = q0 + 1;   // one hit always fits: CAPE >= 256 >= its locations
+                    __syncthreads();
+                    for (int q = q0 + 2 + tid; q <= nq && q - q0 <= T.CAPH; q += NT) {
+                        const int hq = queue[q - 1];
+                        if (offsA[hq] + hits[hq].nloc - e_base <= T.CAPE) atomicMax(&aggr[8], q);
                     }
                     __syncthreads();
                     q1 = aggr[8];
                 }
-                const int e_end = (q1 < nq) ? offsA[queue[q1]] : offsA[nh];
+                const int e_end = (q1 < nq) ? offsA[queue[q1]] : offsA[nI];
                 nE = e_end - e_base;
                 // entries: one thread per searched hit of the round lists its optimal locations
                 for (int q = q0 + tid; q < q1; q += NT) {
@@ -1418,7 +1562,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     const EntL en = ents[ei];
                     if (BSV == 3) etail[ei] = -0x7FFFFFFF;
                     if (!en.ok) continue;
-                    const int hh = en.hit, r = divH(hh), h = hh - __mul24(r, H), p = h >> 1, X = h & 1;
+                    const int hh = cmode ? (int)clist[en.hit] : (int)en.hit, r = divH(hh), h = hh - __mul24(r, H), p = h >> 1, X = h & 1;
                     const unsigned char *cwt = codes + __mul24(r * 2 + X, CS) + en.tj0;
                     unsigned *dm = dmask + __mul24(__mul24(en.slot >> logG, kidx + 1), MBW) + w;
                     if constexpr (BSV == 3) {
@@ -1468,7 +1612,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             for (int item = tid; item < (nE << logG); item += NT) {
                 const EntL en = ents[item >> logG];
                 int bi = item & (G - 1);
-                int hh = en.hit, r = divH(hh), h = hh - __mul24(r, H), p = h >> 1, X = h & 1;
+                int hh = cmode ? (int)clist[en.hit] : (int)en.hit, r = divH(hh), h = hh - __mul24(r, H), p = h >> 1, X = h & 1;
                 int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
                 if (bi >= nb || !en.ok) continue;
                 int gb = LP.pbc[LP.pbc_off[p] + bi];
@@ -1527,7 +1671,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                             int t = -0x7FFFFFFF;
                             if (ne == 1) t = etail[e0];
                             else {
-                                const int r = divH(item), h = item - __mul24(r, H), p = h >> 1, X = h & 1;
+                                const int dn = cmode ? (int)clist[item] : item;
+                                const int r = divH(dn), h = dn - __mul24(r, H), p = h >> 1, X = h & 1;
                                 const int base = end_geom(lensC[r], S).base, bsm = P->bs_m;
                                 const unsigned *reb = bsre + __mul24(p, T.BSP);   // MBW == 1 on this path
                                 unsigned GM[4], prev[4] = {0u, 0u, 0u, 0u}, lower = 0;
@@ -1640,19 +1785,20 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             STAMP(5);
             q0 = q1;
         }
+        }   // live
 
         }   // have
         // the encode target buffers: namask is OR-ed into, the next tile's orientation votes are counted up
         for (int i = tid; i < R * 2 * MW; i += NT) namask[i] = 0;
         for (int i = tid; i < R; i += NT) { ocnt[(par ^ 1) * R + i] = 0; rflag[(par ^ 1) * R + i] = 0; }
-        if (tid == 0) aggr[9] = (int)popped;
+        if (tid == 0) { aggr[9] = (int)popped; aggr[11] = 0; }
         __syncthreads();
         const uint32_t nxt = (uint32_t)aggr[9];
         STAMP(0);
 
         // ---- phase 4 || phase 1: the scorer of this tile (lowest wave(s), one lane per read) runs beside the
         // load + encode of the next tile (all other waves; every wave while the pipeline fills)
-        if (have && wave < SW) {
+        if (live && wave < SW) {
             unsigned long long t_sc0 = 0;
             if (timing) t_sc0 = clock64();   // diagnostic: the scorer wave's own time inside the shared region
             // G lanes per read while the tile is smaller than the wave (R <= 32: panels with many primers)
@@ -1661,6 +1807,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             if (r < nr) {
                 int L = lensC[r];
                 bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
+                const unsigned long long pm_r = pmask[r];   // (the lanes sharing a read sit in one wave: all have read it
+                if (cfilt && sub == 0) pmask[r] = 0ull;     //  when the lead lane clears it for the next tile)
                 if (sub == 0) atomicAdd(&aggr[0], 1);
                 if (filtered) {
                     if (sub == 0) {
@@ -1673,7 +1821,11 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     }
                 } else {
                     ReadCtx c;
-                    c.P = P; c.LP = LP; c.hits = hits + r * H; c.tiem = tiem + r * H * MBW; c.MBW = MBW; c.L = L; c.S = S;
+                    c.P = P; c.LP = LP; c.MBW = MBW; c.L = L; c.S = S;
+                    if (cmode) { c.hits = hits; c.tiem = tiem; c.hmap = hmap + r * H; }
+                    else { c.hits = hits + r * H; c.tiem = tiem + r * H * MBW; c.hmap = nullptr; }
+                    c.hcand = cfilt ? hcand : nullptr;
+                    c.pm = pm_r;
                     c.g = end_geom(L, S);
                     int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
                     int ori = 3;
@@ -1696,12 +1848,13 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             if (timing) tacc[9] += clock64() - t_sc0;
         } else if (nxt < n_tiles) {
             // ---- phase 1 (of the NEXT tile): windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
-            const int wid = have ? tid - 64 * SW : tid, nw = have ? NT - 64 * SW : NT;
+            const int wid = live ? tid - 64 * SW : tid, nw = live ? NT - 64 * SW : NT;
             const bool timing_enc = P->dbg_phase != nullptr && tid == 64 * SW;   // diagnostic: this wave's own encode time
             unsigned long long t_enc0 = 0;
             if (timing_enc) t_enc0 = clock64();
-            const uint32_t r0n = nxt * R;
-            const int nrn = (int)((n_reads - r0n) < (uint32_t)R ? (n_reads - r0n) : (uint32_t)R);
+            uint32_t r0n;
+            int nrn;
+            tile_span(nxt, r0n, nrn);
             int *lensN = lensL + (par ^ 1) * R;
             if (wid < nrn) lensN[wid] = lens[r0n + wid];
             // one 16-byte chunk: generic per-byte encode (short reads, search_len not a multiple of 16)
@@ -1774,16 +1927,16 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         __syncthreads();
         STAMP(6);
         // result records: LDS -> HBM, 16 bytes per lane, fully coalesced
-        if (have) {
+        if (live) {
             const uint4 *srcv = (const uint4 *)opsL;
             uint4 *dstv = (uint4 *)(ops + r0);
             for (int i = tid; i < nr * 2; i += NT) dstv[i] = srcv[i];
         }
         // ---- optional parity dump
-        if (have && dbg_hits) {
+        if (live && dbg_hits) {
             for (int item = tid; item < nh; item += NT) {
                 int r = divH(item);
-                const HitL &hl = hits[item];
+                const HitL &hl = hits[cmode ? (int)hmap[item] : item];
                 EndGeom g = end_geom(lensC[r], S);
                 smx_hit o;
                 o.pdist = hl.pdist; o.nloc = hl.nloc;
@@ -1811,18 +1964,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 #undef STAMP
     // block aggregates -> global counters
     if (tid < 8 && aggr[tid]) atomicAdd(&counts[tid], (unsigned long long)aggr[tid]);
-    // The launch counters re-arm themselves: tile_counter = {tile queue head, -, finished workgroups, extra records}.  The last workgroup to get here publishes the extra-record count and zeroes the block, so a launch
-    // needs no memset in front of it (two small fills per batch were ~2 % of a 0.4 ms launch).
     __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        const unsigned prev = atomicAdd(tile_counter + 2, 1u);
-        if (prev == gridDim.x - 1) {
-            __threadfence();
-            *n_extra = atomicAdd(tile_counter + 3, 0u);
-            tile_counter[0] = 0; tile_counter[2] = 0; tile_counter[3] = 0;
-        }
-    }
+    if (tid == 0) workgroup_done();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1913,16 +2056,26 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
                                 const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops,
                                 smx_op *d_extra, uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts,
                                 smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter, int use_slots,
-                                const unsigned *d_pre, uint32_t npad) {
+                                const unsigned *d_pre, uint32_t npad, const smx::DemuxAux *aux_in) {
     hipStream_t s = (hipStream_t)stream;
-    // d_tile_counter = {tile queue head, -, finished workgroups, extra records}: zero at allocation, re-armed by
-    // the last workgroup of every launch
+    smx::DemuxAux aux = {nullptr, nullptr, 0, 0, 0, 0};
+    if (aux_in) aux = *aux_in;
+    if (aux.nitems > 0 && (use_slots || !d_pre || !aux.match || !aux.ovf_list || aux.nitems > 256)) return (int)hipErrorInvalidValue;
+    if (aux.redo && (!aux.ovf_list || aux.Rc < 1)) return (int)hipErrorInvalidValue;
+    // d_tile_counter = {tile queue head, overflow tiles, finished workgroups, extra records}: zero at allocation, re-armed
+    // by the last workgroup of every launch (of the last launch of a chain)
     // one instantiation per (primer word width, barcode scan variant); slots mode never uses the bit-sliced scan
     const int bsv = (use_slots || !P->bs_ok) ? 0 : (P->kidx < 4 ? (P->trim == SMX_TRIM_TAILS ? 3 : 1) : 2);
+    if (aux.nitems > 0 && use64) return (int)hipErrorInvalidValue;   // (the prescan serves primers of <= 31 nt only)
 #define SMX_LAUNCH(PWT, BSVV)                                                                                         \
+    if (aux.nitems > 0)                                                                                               \
+        hipLaunchKernelGGL((smx::demux_kernel<unsigned, 256, BSVV, 1>), dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
+                       d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits, d_bdist,        \
+                       d_tile_counter, use_slots, d_pre, npad, aux);                                                  \
+    else                                                                                                              \
     hipLaunchKernelGGL((smx::demux_kernel<PWT, 256, BSVV>), dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
                        d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits, d_bdist,        \
-                       d_tile_counter, use_slots, d_pre, npad)
+                       d_tile_counter, use_slots, d_pre, npad, aux)
     if (R > 64) return (int)hipErrorInvalidValue;
     if (use64) { if (bsv == 0) SMX_LAUNCH(unsigned long long, 0); else if (bsv == 1) SMX_LAUNCH(unsigned long long, 1); else if (bsv == 2) SMX_LAUNCH(unsigned long long, 2); else SMX_LAUNCH(unsigned long long, 3); }
     else { if (bsv == 0) SMX_LAUNCH(unsigned, 0); else if (bsv == 1) SMX_LAUNCH(unsigned, 1); else if (bsv == 2) SMX_LAUNCH(unsigned, 2); else SMX_LAUNCH(unsigned, 3); }
@@ -1931,9 +2084,9 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
 }
 
 extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta,
-                                      int kidx, int slots, int bs) {
-    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs).total
-                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs).total;
+                                      int kidx, int slots, int bs, int nitems) {
+    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, 0, 0, nitems).total
+                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, 0, 0, nitems).total;
 }
 
 extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
@@ -1947,7 +2100,21 @@ extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
         hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (r != hipSuccess) e = r;
     }
+    if (!use64) {
+        const void *cf[4] = {(const void *)smx::demux_kernel<unsigned, 256, 0, 1>, (const void *)smx::demux_kernel<unsigned, 256, 1, 1>,
+                             (const void *)smx::demux_kernel<unsigned, 256, 2, 1>, (const void *)smx::demux_kernel<unsigned, 256, 3, 1>};
+        for (const void *f : cf) {
+            hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (r != hipSuccess) e = r;
+        }
+    }
     return (int)e;
+}
+
+extern "C" int smx_query_occupancy_compact(int bsv, size_t lds_bytes, int *blocks_per_cu) {
+    const void *cf[4] = {(const void *)smx::demux_kernel<unsigned, 256, 0, 1>, (const void *)smx::demux_kernel<unsigned, 256, 1, 1>,
+                         (const void *)smx::demux_kernel<unsigned, 256, 2, 1>, (const void *)smx::demux_kernel<unsigned, 256, 3, 1>};
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, cf[bsv < 0 || bsv > 3 ? 0 : bsv], 256, lds_bytes);
 }
 
 extern "C" int smx_query_occupancy(int use64, int bsv, size_t lds_bytes, int *blocks_per_cu) {

@@ -8,7 +8,9 @@
 //   addresses, the 5-plane gap counter, the 32 flag words of the current 16-column chunk and two four-column groups of
 //   plane words in registers.  Output: one flag word per (primer, end, 16-column chunk, read), layout
 //   [tile][primer * 2 + end][chunk][read in tile] (prescan_decode turns the chunk words of one alignment into
-//   distance / ends).
+//   distance / ends), plus one match word per (tile, primer * 2 + end, 32-read group): bit r = that read reaches the
+//   primer's threshold somewhere in the window ([tile][primer * 2 + end][group]; the demux kernel of a many-primer panel
+//   keeps per-alignment state for the flagged alignments only).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -106,7 +108,8 @@ __global__ __launch_bounds__(256) void prescan_transpose_kernel(int S, const uin
 #endif
 template <int MR, int NX>
 __global__ __launch_bounds__(64, SMX_PRE_WAVES) void prescan_dp_kernel(PreDesc D, const unsigned *__restrict__ gplanes,
-                                                           unsigned *__restrict__ out, uint32_t ntiles) {
+                                                           unsigned *__restrict__ out, unsigned *__restrict__ match,
+                                                           uint32_t ntiles) {
     __shared__ unsigned scratch[PRE_SCRATCH];
     const int lane = threadIdx.x;
     const int CH = D.S >> 4;
@@ -117,7 +120,8 @@ __global__ __launch_bounds__(64, SMX_PRE_WAVES) void prescan_dp_kernel(PreDesc D
         const int g = lane >> 1, X = lane & 1;
         // tile-major output: the CH x 2 NP words of a read sit within its tile's 4 * 2 NP * CH KB
         prescan_dp<MR, NX>(gplanes + (size_t)tile * CH * 8 * 64 * 4, scratch, lane, CH, D, p,
-                           out + ((size_t)tile * (2 * D.NP) + (size_t)(2 * p + X)) * CH * PRE_TILE + (uint32_t)g * 32u, PRE_TILE);
+                           out + ((size_t)tile * (2 * D.NP) + (size_t)(2 * p + X)) * CH * PRE_TILE + (uint32_t)g * 32u, PRE_TILE,
+                           match + ((size_t)tile * (2 * D.NP) + (size_t)(2 * p + X)) * PRE_G + (uint32_t)g);
     }
 }
 
@@ -141,7 +145,7 @@ static const void *prescan_fn(int mr, int nx) {
 // grid_t / grid_d = resident workgroups of the two kernels (the caller sizes them)
 extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int grid_t, size_t lds_t, int grid_d, void *stream,
                                   const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride,
-                                  unsigned *d_planes, unsigned *d_out, void *ev_mid) {
+                                  unsigned *d_planes, unsigned *d_out, unsigned *d_match, void *ev_mid) {
     static_assert(smx::PRE_MAXROWS == 31 && smx::PRE_MAXSYM == 8, "variant table");
     const uint32_t ntiles = (n_reads + smx::PRE_TILE - 1) / smx::PRE_TILE;
     hipStream_t s = (hipStream_t)stream;
@@ -153,7 +157,7 @@ extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int gri
     const int mrv = mr <= 24 ? 24 : 31, nxv = nx > 0 ? 4 : 0;
 #define X(MRV, NXV)                                                                                            \
     if (mrv == MRV && nxv == NXV)                                                                              \
-        hipLaunchKernelGGL((smx::prescan_dp_kernel<MRV, NXV>), dim3(grid_d), dim3(64), 0, s, *D, d_planes, d_out, ntiles);
+        hipLaunchKernelGGL((smx::prescan_dp_kernel<MRV, NXV>), dim3(grid_d), dim3(64), 0, s, *D, d_planes, d_out, d_match, ntiles);
     SMX_PRE_VARIANTS(X)
 #undef X
     return (int)hipGetLastError();

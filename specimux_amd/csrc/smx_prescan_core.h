@@ -220,9 +220,8 @@ SMX_HD void prescan_write_occ(unsigned *sc, unsigned b0, unsigned b1, const unsi
 // the unrolled rows instead cost hundreds of register copies per column).
 template <int MR, int NX>
 SMX_HD void prescan_dp(const unsigned *gpl, unsigned *scratch, int lane, int CH, const PreDesc &D, int p, unsigned *wout,
-                       size_t cstride) {
-    const int m = D.m[p], skip = MR - m, nsym = D.nsym;
-    (void)m;
+                       size_t cstride, unsigned *mout) {
+    const int m = D.m[p], skip = MR - m;
     unsigned Pv[MR], Mv[MR];
     int aoff[MR];
 #pragma unroll
@@ -236,6 +235,7 @@ SMX_HD void prescan_dp(const unsigned *gpl, unsigned *scratch, int lane, int CH,
 #pragma unroll
         for (int b = 0; b < 4; b++) xm[x][b] = ((D.symmask[p][4 + x] >> b) & 1) ? ~0u : 0u;   // unused symbols have an empty mask
     unsigned g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, zero = ~0u;   // gap = score - running minimum, starts at 0
+    unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0;               // number of new minima so far (best = m - that), bit-sliced
     constexpr int bufw = PRE_SCRATCH / 2;   // compile-time buffer stride: the second buffer is an immediate offset
     unsigned *sc0 = scratch + lane, *sc1 = scratch + bufw + lane;
     sc0[PRE_MAXSYM * 64] = ~0u; sc1[PRE_MAXSYM * 64] = ~0u;   // the inert rows' Eq word (a row no symbol uses)
@@ -325,6 +325,12 @@ SMX_HD void prescan_dp(const unsigned *gpl, unsigned *scratch, int lane, int CH,
             tt = ~g3 & bw; g3 ^= bw; bw = tt;
             g4 ^= bw;
             zero = ~(g0 | g1 | g2 | g3 | g4);
+            cy = lt;
+            tt = n0 & cy; n0 ^= cy; cy = tt;
+            tt = n1 & cy; n1 ^= cy; cy = tt;
+            tt = n2 & cy; n2 ^= cy; cy = tt;
+            tt = n3 & cy; n3 ^= cy; cy = tt;
+            n4 ^= cy;
             fl[t] = lt;
             fl[16 + t] = zero;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -339,6 +345,21 @@ SMX_HD void prescan_dp(const unsigned *gpl, unsigned *scratch, int lane, int CH,
 #else
         for (int r = 0; r < 32; r++) wout[(size_t)ch * cstride + r] = fl[r];
 #endif
+    }
+    // match word: bit r = read r reaches distance <= k somewhere in the S columns  <=>  new minima >= m - k (bit-sliced
+    // compare against the uniform threshold).  For a read shorter than the window this is a superset of "matches within
+    // its own columns" (a minimum over fewer columns is not smaller): the consumer uses it to skip alignments only.
+    {
+        const unsigned thr = (unsigned)(m - (int)D.k[p]);
+        const unsigned nb[5] = {n0, n1, n2, n3, n4};
+        unsigned gt = 0u, eq = ~0u;
+#pragma unroll
+        for (int b = 4; b >= 0; b--) {
+            const unsigned tb = ((thr >> b) & 1u) ? ~0u : 0u;
+            gt |= eq & nb[b] & ~tb;
+            eq &= ~(nb[b] ^ tb);
+        }
+        *mout = gt | eq;
     }
 }
 

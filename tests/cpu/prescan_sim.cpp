@@ -128,8 +128,9 @@ int main(int argc, char **argv) {
     for (int p = 0; p < NP; p++)
         for (int lane = 0; lane < 64; lane++) {   // phase 3: lane = (group, end)
             const int g = lane >> 1, X = lane & 1;
-            if (D.m[p] <= 24) prescan_dp<24, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32);
-            else prescan_dp<31, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32);
+            unsigned mword = 0;
+            if (D.m[p] <= 24) prescan_dp<24, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32, &mword);
+            else prescan_dp<31, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32, &mword);
             for (int r = 0; r < 32; r++) {
                 const int read = g * 32 + r;
                 std::string text;
@@ -154,6 +155,11 @@ int main(int argc, char **argv) {
                 const int best = CH == 5 ? prescan_decode<5>(words.data() + r, 32, CH, MW, m, ks[p], NV, mrow, &jstar, &nloc)
                                          : prescan_decode<0>(words.data() + r, 32, CH, MW, m, ks[p], NV, mrow, &jstar, &nloc);
                 if (best != run) ok = false;
+                // (3) the match word: exact for full windows, a superset for short reads
+                {
+                    const bool mb = (mword >> r) & 1u;
+                    if (NV == S ? mb != (run <= ks[p]) : (run <= ks[p] && !mb)) ok = false;
+                }
                 if (run <= ks[p]) {
                     matched++;
                     int ejs = -1, en = 0;

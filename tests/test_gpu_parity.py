@@ -660,3 +660,38 @@ def test_forced_small_barcode_rounds(c2, monkeypatch):
         both = Both(pf, sf, **fl)
         both.assert_hits_equal(reads[:100], f"caps {fl}")
         both.assert_ops_equal(reads, f"caps {fl}")
+
+
+@pytest.mark.parametrize("env", [dict(), dict(SMX_COMPACT_ITEMS="40"), dict(SMX_COMPACT_ITEMS="16", SMX_COMPACT_R="24"),
+                                 dict(SMX_COMPACT="0")], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
+def test_compact_tiles_many_primer_panel(lib, c3, monkeypatch, env):
+    """The lean kernel's compact mode (panels with many primers: per-alignment records only for the alignments the
+    prescan's match words flag) and the dense redo launch behind it.  Default sizing, a record capacity small enough
+    that most tiles overflow into the redo launch, a tile size that is not a power of two, and compact mode off: the
+    same records and hit tables as the oracle every time -- including reads with N (not covered by the prescan: every
+    alignment of such a read takes a record) and short reads."""
+    from specimux_amd import synth
+    pan, (pf, sf) = c3
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rs = synth.make_reads(pan, 1800, 909, insert_mean=900, insert_sd=250, windows_only=False, n_frac=0.04)
+    reads = reads_from_set(rs, range(1800), 80)
+    short = synth.make_reads(pan, 120, 910, insert_mean=40, insert_sd=30, windows_only=False)
+    reads += reads_from_set(short, range(120), 80, prefix="s")
+    for fl in (dict(), dict(trim="tails"), dict(dereplicate="none", trim="primers")):
+        both = Both(pf, sf, **fl)
+        both.assert_hits_equal(reads[:200] + reads[-60:], f"compact {env} {fl}", lean=True)
+        both.assert_ops_equal(reads, f"compact {env} {fl}")
+
+
+def test_compact_tiles_forced_on_two_primer_panel(lib, c2, monkeypatch):
+    """Compact mode forced onto the 2-primer panel (where the default never uses it), with the edge-case reads."""
+    from specimux_amd import synth
+    pan, (pf, sf) = c2
+    monkeypatch.setenv("SMX_COMPACT_ITEMS", "96")
+    rs = synth.make_reads(pan, 900, 77, windows_only=False)
+    reads = reads_from_set(rs, range(900), 80) + [r for r in _edge_reads(pan) if r[0] != "u_base"]
+    for fl in (dict(), dict(disable_preorient=True)):
+        both = Both(pf, sf, **fl)
+        both.assert_hits_equal(reads[:150], f"compact c2 {fl}", lean=True)
+        both.assert_ops_equal(reads, f"compact c2 {fl}")

@@ -116,7 +116,8 @@ struct smx_panel {
     smx::DevPanel hp;                 // scalar fields valid; pointers filled at upload
     std::vector<unsigned char> blob;  // host image of the device allocation
     size_t o_ppeq, o_prpeq, o_bpeq, o_lut, o_pm, o_pk, o_pdir, o_pfidx, o_pbc_off, o_pbc, o_bm, o_pair_f, o_pair_r,
-        o_pair_pool, o_pairhead, o_spec_next, o_p1m, o_p2m, o_spec_pool, o_bsre;
+        o_pair_pool, o_pairhead, o_spec_next, o_p1m, o_p2m, o_spec_pool, o_bsre, o_pairrec = 0, o_specrec = 0;
+    bool has_rec = false;
     int use64 = 0;
     int R = 0;          // lean mode tile (no per-barcode slots)
     size_t lds = 0;
@@ -326,6 +327,14 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     P->o_pair_f = blob_add(B, pair_f); P->o_pair_r = blob_add(B, pair_r); P->o_pair_pool = blob_add(B, pair_pool);
     P->o_pairhead = blob_add(B, pairhead); P->o_spec_next = blob_add(B, spec_next);
     P->o_p1m = blob_add(B, p1m); P->o_p2m = blob_add(B, p2m); P->o_spec_pool = blob_add(B, spec_pool);
+    if (NB <= 1024) {   // packed lookup tables (32 bytes per barcode pair: 32 MiB at 1024 barcodes)
+        std::vector<smx::SpecRec> specrec(NS), pairrec((size_t)NB * NB);
+        for (int s2 = 0; s2 < NS; s2++) specrec[s2] = {p1m[s2], p2m[s2], s2, spec_next[s2], spec_pool[s2], 0};
+        for (size_t k2 = 0; k2 < pairrec.size(); k2++)
+            pairrec[k2] = pairhead[k2] >= 0 ? specrec[pairhead[k2]] : smx::SpecRec{0ull, 0ull, -1, -1, -1, 0};
+        P->o_pairrec = blob_add(B, pairrec); P->o_specrec = blob_add(B, specrec);
+        P->has_rec = true;
+    }
     P->o_bsre = blob_add(B, bsre);
 
     P->use64 = maxm > 32 ? 1 : 0;
@@ -492,6 +501,8 @@ static int ensure_device(smx_panel *P) {
     h.pairhead = (const int *)(b + P->o_pairhead); h.spec_next = (const int *)(b + P->o_spec_next);
     h.spec_p1m = (const unsigned long long *)(b + P->o_p1m); h.spec_p2m = (const unsigned long long *)(b + P->o_p2m);
     h.spec_pool = (const int *)(b + P->o_spec_pool);
+    h.pairrec = P->has_rec ? (const smx::SpecRec *)(b + P->o_pairrec) : nullptr;
+    h.specrec = P->has_rec ? (const smx::SpecRec *)(b + P->o_specrec) : nullptr;
     h.bs_re = (const unsigned *)(b + P->o_bsre);
     if (std::max(std::max(P->lds, P->lds_slots), P->lds_c) > 64 * 1024) {
         const size_t lim = std::max(std::max(P->lds, P->lds_slots), P->lds_c);

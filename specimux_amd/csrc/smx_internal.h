@@ -12,6 +12,13 @@ namespace smx {
 // Order matters only for the LUTs built in smx_api.cpp.
 static const char kCodeChars[16] = {'A', 'C', 'G', 'T', 'N', 'R', 'Y', 'K', 'M', 'S', 'W', 'B', 'D', 'H', 'V', 0};
 
+// One specimen as the scorer needs it, 32 bytes: two of these tables -- per (b1, b2) barcode pair the FIRST specimen in
+// file order (spec = -1: none), per specimen its own record -- so that specimen_exact is one load in the usual case.
+struct SpecRec {
+    unsigned long long p1m, p2m;   // forward / reverse primers the specimen is registered with (bit = primer index)
+    int spec, next, pool, pad;     // specimen index, next specimen with the same barcode pair (-1: none), its pool
+};
+
 // All pointers are DEVICE pointers (one allocation, see smx_api.cpp).  Passed to kernels by value.
 struct DevPanel {
     int NP, NB, NS, NPAIR;
@@ -36,6 +43,7 @@ struct DevPanel {
     const int *spec_next;                 // chain in file order
     const unsigned long long *spec_p1m, *spec_p2m;
     const int *spec_pool;
+    const SpecRec *pairrec, *specrec;     // packed copies of the five tables above (nullptr for very large barcode sets)
     // bit-sliced barcode scan (lean mode): all barcodes one length bs_m <= 16, k <= 7.
     // bs_re[((p * 16 + row) * 16 + code) * MBW + w] = bitmask over primer p's barcode list: barcode_rc[row] eq code
     int bs_ok, bs_m;

@@ -508,6 +508,21 @@ struct ReadCtx {
     const unsigned short *hmap;   // compact mode: this read's alignment -> record; nullptr: record = alignment
     const unsigned long long *hcand;   // per alignment: bitmask of the candidates it belongs to; nullptr: look at every candidate
     unsigned long long pm;        // this read's alignments with a primer match (bit h)
+    unsigned long long live;      // candidates (pair * 2 + orientation) worth looking at: one of their alignments matched, and
+                                  // the orientation is allowed; all ones when there is no candidate table (hcand == nullptr)
+    // Panels with many primer pairs: a candidate scores > 0 only if one of its two alignments found its primer, so only the
+    // candidates of this read's matched alignments are looked at (a handful of the 2 * NPAIR).  Nothing else changes: every
+    // quantity the scorers compute is a function of the candidates with a positive score.
+    __device__ __forceinline__ void set_live(int ori) {
+        live = ~0ull;
+        if (hcand) {
+            live = 0ull;
+            for (unsigned long long m = pm; m; m &= m - 1ull) live |= hcand[__ffsll((long long)m) - 1];
+            if (ori == 2) live &= 0xAAAAAAAAAAAAAAAAull;        // reverse-complement candidates only (odd ids)
+            else if (ori == 1) live &= 0x5555555555555555ull;
+        }
+    }
+    __device__ __forceinline__ bool cand_live(int ci) const { return !hcand || ((live >> ci) & 1ull); }
     int MBW;
     __device__ __forceinline__ int rec(int h) const { return hmap ? (int)hmap[h] : h; }
     __device__ __forceinline__ const HitL &hit(int h) const { return hits[rec(h)]; }
@@ -551,14 +566,24 @@ __device__ __forceinline__ int cand_score(const CandView &v) {   // demultiplex.
     return 0;
 }
 
-// next tied barcode (local index >= from) of hit h in canonical order; -1 when exhausted.
+// next tied barcode (local index >= from) of hit h in canonical order; -1 when exhausted.  (Find-first-set on the tie
+// mask words: the scorers enumerate tie sets in nested loops, and a bit-by-bit scan of up to maxB positions per call was
+// most of the general scorer's instruction stream.)
 __device__ inline int next_tied(const ReadCtx &c, int h, int from) {
     int p = h >> 1;
     int nb = c.LP.pbc_off[p + 1] - c.LP.pbc_off[p];
+    if (from >= nb) return -1;
     const unsigned *tm = c.tiem + c.rec(h) * c.MBW;
-    for (int i = from; i < nb; i++)
-        if ((tm[i >> 5] >> (i & 31)) & 1) return i;
-    return -1;
+    int w = from >> 5;
+    unsigned word = tm[w] & (~0u << (from & 31));
+    for (;;) {
+        if (word) {
+            const int i = w * 32 + __ffs((int)word) - 1;
+            return i < nb ? i : -1;
+        }
+        if (++w >= c.MBW) return -1;
+        word = tm[w];
+    }
 }
 __device__ __forceinline__ int global_bc(const ReadCtx &c, int h, int local) {
     return c.LP.pbc[c.LP.pbc_off[h >> 1] + local];
@@ -570,9 +595,27 @@ __device__ inline bool tied_has_global(const ReadCtx &c, int h, int gb) {
 }
 
 // Specimens.specimen_for_exact_match (databases.py:232-245): first specimen in file order.
-__device__ inline int specimen_exact(const DevPanel *P, int gb1, int gb2, int f, int r) {
+// With the packed tables (DevPanel::pairrec) the usual lookup is ONE 32-byte load -- the (b1, b2) cell holds the first
+// specimen's whole record -- instead of three dependent ones (head of the chain, its primer masks, its pool): the scorer
+// wave sits on a tile's critical path and every dependent global load is most of a microsecond.
+__device__ inline int specimen_exact(const DevPanel *P, int gb1, int gb2, int f, int r, int *pool_out = nullptr) {
+    if (P->pairrec) {
+        SpecRec rec = P->pairrec[(size_t)gb1 * P->NB + gb2];
+        while (rec.spec >= 0) {
+            if (((rec.p1m >> f) & 1) && ((rec.p2m >> r) & 1)) {
+                if (pool_out) *pool_out = rec.pool;
+                return rec.spec;
+            }
+            if (rec.next < 0) break;
+            rec = P->specrec[rec.next];
+        }
+        return -1;
+    }
     for (int s = P->pairhead[gb1 * P->NB + gb2]; s >= 0; s = P->spec_next[s])
-        if (((P->spec_p1m[s] >> f) & 1) && ((P->spec_p2m[s] >> r) & 1)) return s;
+        if (((P->spec_p1m[s] >> f) & 1) && ((P->spec_p2m[s] >> r) & 1)) {
+            if (pool_out) *pool_out = P->spec_pool[s];
+            return s;
+        }
     return -1;
 }
 
@@ -698,6 +741,7 @@ __device__ inline void emit_partial_or_unknown(Emitter &E, const CandView &v, in
     for (int _pair = 0; _pair < (c).P->NPAIR; _pair++)                                   \
         for (int _o = 0; _o < 2; _o++) {                                                 \
             if ((_o == 0 && (ori) == 2) || (_o == 1 && (ori) == 1)) continue;            \
+            if (!(c).cand_live(_pair * 2 + _o)) continue;                                \
             CandView v = cand_view((c), _pair, _o);                                      \
             if (!(v.p1 || v.p2)) continue;                                               \
             if (cand_score(v) != (best)) continue;                                       \
@@ -748,16 +792,7 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
     // ---- select_best_matches (demultiplex.py:216-259): best score, how many carry it, the first of them
     int best = 0, nbest = 0, first = 0x7FFF;
     const int ncand = P->NPAIR * 2;
-    // Panels with many primer pairs: a candidate scores > 0 only if one of its two alignments found its primer, so only the
-    // candidates of this read's matched alignments are looked at (a handful of the 2 * NPAIR); nothing else changes --
-    // best / nbest / first are functions of the candidates with a positive score.
-    unsigned long long live = ~0ull;
-    if (c.hcand) {
-        live = 0ull;
-        for (unsigned long long m = c.pm; m; m &= m - 1ull) live |= c.hcand[__ffsll((long long)m) - 1];
-        if (ori == 2) live &= 0xAAAAAAAAAAAAAAAAull;        // reverse-complement candidates only (odd ids)
-        else if (ori == 1) live &= 0x5555555555555555ull;
-    }
+    const unsigned long long live = c.live;   // (ReadCtx::set_live)
     if (c.hcand) {
         for (unsigned long long m = live; m; m &= m - 1ull) {
             const int ci = __ffsll((long long)m) - 1;
@@ -785,12 +820,14 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
     // The divergent case analysis below only picks the parameters of the ONE record this read emits; the record
     // itself is built once, after the lanes have converged again (emit_op is by far the longest piece of code here).
     bool has_v = true;
-    int pair = only_pair, o = only_o, sample = -1, rtype = SMX_R_UNKNOWN, barcode = -1, pool = -2;   // pool -2: the pair's
+    int pair = only_pair, o = only_o, sample = -1, rtype = SMX_R_UNKNOWN, barcode = -1;
     const bool lead = sub == 0;   // the lane that analyses the winner and emits; its partners only take part in the shuffles
     unsigned xflags = 0;
     int more1 = -1, more2 = -1, more3 = -1;   // further specimens of a tied full match
+    int repeat = 1;                           // identical UNKNOWN records (one per tied barcode of a partial match)
+    int spool = -2;                           // the specimen's pool when the lookup already brought it along
     if (best == 0) {   // no candidate at all (demultiplex.py:202-210)
-        has_v = false; pair = 0; o = 0; pool = -1;
+        has_v = false; pair = 0; o = 0;
     } else if (best <= 2 && nbest > 1) {
         // several primer-only candidates (typically both orientations of one pair): no barcode logic involved.
         // dereplicate=best -> dereplicate_unknown_matches: stable minimum of (-primer_count, primer_dist, file index);
@@ -811,6 +848,33 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
             if (ok < wkey || (ok == wkey && oc < wci)) { wkey = ok; wci = oc; }
         }
         pair = wci >> 1; o = wci & 1;
+    } else if (best <= 4 && nbest > 1) {
+        // several partial candidates (typically the pairs that share one primer, when only that primer's end of the read is
+        // good).  dereplicate_partial_matches (demultiplex.py:396-477) groups them by (direction, barcode); when every one
+        // of them has a single untied barcode and it is the same (direction, barcode) for all, there is one group and its
+        // winner -- stable minimum of key_partial -- is the one record.  Anything else: the general scorer.
+        if (!lead) return true;
+        if (P->derep != SMX_DEREP_BEST) return false;
+        int gdir = -1, ggb = -1, wkey = 0x7FFFFFFF, wci = -1;
+        for (int ci = 0; ci < ncand; ci++) {
+            if (!((live >> ci) & 1ull)) continue;
+            if (((ci & 1) == 0 && ori == 2) || ((ci & 1) == 1 && ori == 1)) continue;
+            const CandView v = cand_view(c, ci >> 1, ci & 1);
+            if (cand_score(v) != best) continue;
+            const bool fwd = v.b1;
+            const int h = fwd ? v.h1 : v.h2;
+            const HitL &x = c.hit(h);
+            if (x.ntied != 1) return false;
+            const int gb = global_bc(c, h, x.first_tied);
+            if (gdir < 0) { gdir = fwd ? 1 : 0; ggb = gb; }
+            else if (gdir != (fwd ? 1 : 0) || ggb != gb) return false;
+            const int k = key_partial(c.LP, v, fwd);
+            if (k < wkey) { wkey = k; wci = ci; }
+        }
+        pair = wci >> 1; o = wci & 1;
+        const CandView w = cand_view(c, pair, o);   // resolve_specimen of the winner (demultiplex.py:576-589)
+        if (w.b1 && !w.b2) { rtype = SMX_R_PARTIAL_FWD; barcode = ggb; }
+        else if (w.b2 && !w.b1) { rtype = SMX_R_PARTIAL_REV; barcode = ggb; }
     } else {
         if (!lead) return true;
         if (nbest != 1) return false;
@@ -820,8 +884,14 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
         if (best <= 2) {
             // dereplicate_unknown_matches / resolve_specimen: UNKNOWN either way
         } else if (best <= 4) {   // one (direction, barcode) group: resolve_specimen (demultiplex.py:576-589)
-            if (!(t1 && t2)) return false;
-            if (v.b1 && !v.b2) { rtype = SMX_R_PARTIAL_FWD; barcode = global_bc(c, v.h1, a.first_tied); }
+            if (!(t1 && t2)) {
+                // tied barcodes on the one end that has any: dereplicate_partial_matches makes one group per tied barcode,
+                // each with this candidate as its only member, and resolve_specimen turns each into UNKNOWN (the barcode is
+                // ambiguous): ntied identical records
+                if (P->derep != SMX_DEREP_BEST) return false;
+                repeat = v.b1 ? a.ntied : b.ntied;
+            }
+            else if (v.b1 && !v.b2) { rtype = SMX_R_PARTIAL_FWD; barcode = global_bc(c, v.h1, a.first_tied); }
             else if (v.b2 && !v.b1) { rtype = SMX_R_PARTIAL_REV; barcode = global_bc(c, v.h2, b.first_tied); }
         } else if (P->derep != SMX_DEREP_BEST) {
             // --dereplicate none: resolve_specimen's full branch (demultiplex.py:555-575) for untied barcodes --
@@ -834,12 +904,12 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
                     cnt++;
                     if (first < 0 || sp < first) first = sp;
                 }
-            if (cnt > 0) { sample = first; rtype = cnt > 1 ? SMX_R_MULTIPLE : SMX_R_FULL; pool = P->spec_pool[first]; }
+            if (cnt > 0) { sample = first; rtype = cnt > 1 ? SMX_R_MULTIPLE : SMX_R_FULL; }
             else xflags = SMX_OPF_NO_SPECIMEN;
         } else {
             if (t1 && t2) {
-                int spec = specimen_exact(P, global_bc(c, v.h1, a.first_tied), global_bc(c, v.h2, b.first_tied), v.f, v.r);
-                if (spec >= 0) { sample = spec; rtype = SMX_R_DEREP_FULL; pool = P->spec_pool[spec]; }
+                int spec = specimen_exact(P, global_bc(c, v.h1, a.first_tied), global_bc(c, v.h2, b.first_tied), v.f, v.r, &spool);
+                if (spec >= 0) { sample = spec; rtype = SMX_R_DEREP_FULL; }
                 else xflags = SMX_OPF_NO_SPECIMEN;
             } else {
                 // one candidate, tied barcodes (by far the most frequent reason to leave the single-record path):
@@ -856,16 +926,17 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
                     }
                 if (ns == 0) xflags = SMX_OPF_NO_SPECIMEN;
                 else {
-                    sample = s0; rtype = SMX_R_DEREP_FULL; pool = P->spec_pool[s0];
+                    sample = s0; rtype = SMX_R_DEREP_FULL;
                     more1 = s1; more2 = s2; more3 = s3;
                 }
             }
         }
     }
     if (!lead) return true;
-    if (pool == -2) pool = c.LP.pair_pool[pair];
     const CandView v = cand_view(c, pair, o);
+    const int pool = !has_v ? -1 : (sample >= 0 ? (spool != -2 ? spool : P->spec_pool[sample]) : c.LP.pair_pool[pair]);
     emit_op(E, has_v ? &v : nullptr, pair * 2 + o, sample, rtype, pool, barcode, xflags);
+    for (int e = 1; e < repeat; e++) emit_op(E, &v, pair * 2 + o, -1, SMX_R_UNKNOWN, pool, -1, 0);   // rare
     if (more1 >= 0) {   // rare
         for (int e = 0; e < 3; e++) {
             int sp = e == 0 ? more1 : (e == 1 ? more2 : more3);
@@ -883,6 +954,7 @@ __device__ inline void score_general(Emitter &E, int ori) {
     for (int pair = 0; pair < P->NPAIR; pair++)
         for (int o = 0; o < 2; o++) {
             if ((o == 0 && ori == 2) || (o == 1 && ori == 1)) continue;
+            if (!c.cand_live(pair * 2 + o)) continue;
             CandView v = cand_view(c, pair, o);
             int sc = cand_score(v);
             best = sc > best ? sc : best;
@@ -1830,6 +1902,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
                     int ori = 3;
                     if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
+                    c.set_live(ori);
                     Emitter E;
                     E.c = &c; E.primary = opsL + r; E.extra = extra; E.extra_cap = extra_cap;
                     E.n_extra = tile_counter + 3;   // see the kernel's epilogue
@@ -1887,12 +1960,31 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 // [all tail chunks] so that a wave is (almost always) uniform in role.  Full windows (len >= S):
                 // four LUT lookups -> one packed dword store; the head is written reversed (reverse complement).
                 const int hc = S >> 4, nhead = nrn * hc, S4 = S >> 2;
-                for (int ci = wid; ci < 2 * nhead; ci += nw) {
+                // four chunks per lane and pass, all their loads (window piece, read length) issued before the first is
+                // used: one memory round trip per pass instead of one per chunk (a load inside the per-chunk branch is
+                // waited for before the next one is issued; the encode waves' time is load latency)
+                constexpr int EB = 4;
+                for (int ci0 = wid; ci0 < 2 * nhead; ci0 += EB * nw) {
+                uint4 vb[EB];
+                int Lb[EB];
+#pragma unroll
+                for (int u = 0; u < EB; u++) {
+                    const int ci = ci0 + u * nw < 2 * nhead ? ci0 + u * nw : 2 * nhead - 1;
                     const bool tail = ci >= nhead;
                     const int k = tail ? ci - nhead : ci;
                     const int r = (int)__umulhi((unsigned)k, hcmagic), c = k - __mul24(r, hc);
-                    const uint4 v = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (tail ? S : 0) + 16 * c);
-                    const int L = lens[r0n + r];
+                    vb[u] = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (tail ? S : 0) + 16 * c);
+                    Lb[u] = lens[r0n + r];
+                }
+#pragma unroll
+                for (int u = 0; u < EB; u++) {
+                    const int ci = ci0 + u * nw;
+                    if (ci >= 2 * nhead) break;
+                    const bool tail = ci >= nhead;
+                    const int k = tail ? ci - nhead : ci;
+                    const int r = (int)__umulhi((unsigned)k, hcmagic), c = k - __mul24(r, hc);
+                    const uint4 v = vb[u];
+                    const int L = Lb[u];
                     // ACGT fast path, four bases per dword without the LUT: (ch >> 1) & 3 maps A,C,T,G -> 0,1,2,3; swapping 2 and 3
                     // gives the code, xor 3 the complement's code; one v_perm rebuilds the four letters from the codes and a
                     // compare proves that the dword held nothing but upper-case ACGT (anything else: per-byte LUT path below)
@@ -1913,6 +2005,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     } else {
                         encode_bytes(r, L, (tail ? S : 0) + 16 * c, v);
                     }
+                }
                 }
             } else {
                 const int chunks = stride / 16;

@@ -116,8 +116,7 @@ struct smx_panel {
     smx::DevPanel hp;                 // scalar fields valid; pointers filled at upload
     std::vector<unsigned char> blob;  // host image of the device allocation
     size_t o_ppeq, o_prpeq, o_bpeq, o_lut, o_pm, o_pk, o_pdir, o_pfidx, o_pbc_off, o_pbc, o_bm, o_pair_f, o_pair_r,
-        o_pair_pool, o_pairhead, o_spec_next, o_p1m, o_p2m, o_spec_pool, o_bsre, o_pairrec = 0, o_specrec = 0;
-    bool has_rec = false;
+        o_pair_pool, o_bsre, o_pairrec = 0, o_specrec = 0;
     int use64 = 0;
     int R = 0;          // lean mode tile (no per-barcode slots)
     size_t lds = 0;
@@ -190,6 +189,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     if (NP <= 0 || NB <= 0 || NS <= 0 || NPAIR <= 0) return fail(SMX_ERR_ARG, "empty panel");
     if (NP > 64) return fail(SMX_ERR_UNSUPPORTED, "more than 64 distinct primers (%d)", NP);
     if (NPAIR > 127) return fail(SMX_ERR_UNSUPPORTED, "more than 127 primer pairs (%d)", NPAIR);
+    if (NB > 4096) return fail(SMX_ERR_UNSUPPORTED, "more than 4096 distinct barcodes (%d)", NB);   // (b1, b2) table: 32 B per pair
     if (d->search_len < 1 || d->search_len > 256)
         return fail(SMX_ERR_UNSUPPORTED, "search_len %d outside 1..256", d->search_len);
     if (d->k_index < 0 || d->k_index > 32) return fail(SMX_ERR_UNSUPPORTED, "index edit distance %d outside 0..32", d->k_index);
@@ -325,15 +325,12 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     P->o_pm = blob_add(B, pm); P->o_pk = blob_add(B, pk); P->o_pdir = blob_add(B, pdir); P->o_pfidx = blob_add(B, pfidx);
     P->o_pbc_off = blob_add(B, pbc_off); P->o_pbc = blob_add(B, pbc); P->o_bm = blob_add(B, bm);
     P->o_pair_f = blob_add(B, pair_f); P->o_pair_r = blob_add(B, pair_r); P->o_pair_pool = blob_add(B, pair_pool);
-    P->o_pairhead = blob_add(B, pairhead); P->o_spec_next = blob_add(B, spec_next);
-    P->o_p1m = blob_add(B, p1m); P->o_p2m = blob_add(B, p2m); P->o_spec_pool = blob_add(B, spec_pool);
-    if (NB <= 1024) {   // packed lookup tables (32 bytes per barcode pair: 32 MiB at 1024 barcodes)
+    {   // packed lookup tables (32 bytes per barcode pair)
         std::vector<smx::SpecRec> specrec(NS), pairrec((size_t)NB * NB);
         for (int s2 = 0; s2 < NS; s2++) specrec[s2] = {p1m[s2], p2m[s2], s2, spec_next[s2], spec_pool[s2], 0};
         for (size_t k2 = 0; k2 < pairrec.size(); k2++)
             pairrec[k2] = pairhead[k2] >= 0 ? specrec[pairhead[k2]] : smx::SpecRec{0ull, 0ull, -1, -1, -1, 0};
         P->o_pairrec = blob_add(B, pairrec); P->o_specrec = blob_add(B, specrec);
-        P->has_rec = true;
     }
     P->o_bsre = blob_add(B, bsre);
 
@@ -498,11 +495,8 @@ static int ensure_device(smx_panel *P) {
     h.pbc_off = (const int *)(b + P->o_pbc_off); h.pbc = (const int *)(b + P->o_pbc); h.bm = (const int *)(b + P->o_bm);
     h.pair_f = (const int *)(b + P->o_pair_f); h.pair_r = (const int *)(b + P->o_pair_r);
     h.pair_pool = (const int *)(b + P->o_pair_pool);
-    h.pairhead = (const int *)(b + P->o_pairhead); h.spec_next = (const int *)(b + P->o_spec_next);
-    h.spec_p1m = (const unsigned long long *)(b + P->o_p1m); h.spec_p2m = (const unsigned long long *)(b + P->o_p2m);
-    h.spec_pool = (const int *)(b + P->o_spec_pool);
-    h.pairrec = P->has_rec ? (const smx::SpecRec *)(b + P->o_pairrec) : nullptr;
-    h.specrec = P->has_rec ? (const smx::SpecRec *)(b + P->o_specrec) : nullptr;
+    h.pairrec = (const smx::SpecRec *)(b + P->o_pairrec);
+    h.specrec = (const smx::SpecRec *)(b + P->o_specrec);
     h.bs_re = (const unsigned *)(b + P->o_bsre);
     if (std::max(std::max(P->lds, P->lds_slots), P->lds_c) > 64 * 1024) {
         const size_t lim = std::max(std::max(P->lds, P->lds_slots), P->lds_c);
@@ -596,13 +590,13 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         const size_t need = (size_t)2 * P->hp.NP * (P->hp.S >> 4) * npad * sizeof(unsigned);
         DevBuf &pb = P->pre_recs[slot], &pp = P->pre_planes[slot], &pm = P->pre_match[slot], &ov = P->ovf[slot];
         const size_t need_planes = (size_t)(npad / smx::PRE_TILE) * (P->hp.S >> 4) * 8 * 64 * 4 * sizeof(unsigned);
-        const size_t need_match = (size_t)(npad / smx::PRE_TILE) * 2 * P->hp.NP * smx::PRE_G * sizeof(unsigned);
+        const size_t need_match = P->nitems > 0 ? (size_t)(npad / smx::PRE_TILE) * 2 * P->hp.NP * smx::PRE_G * sizeof(unsigned) : 0;
         const size_t need_ovf = compact ? ((size_t)n_reads / P->Rc + 2) * sizeof(unsigned) : 0;
         if (need > pb.cap || need_planes > pp.cap || need_match > pm.cap || need_ovf > ov.cap) {
             if (pb.p || pp.p) (void)hipStreamSynchronize((hipStream_t)stream);   // earlier launches on this stream still use them
             hipError_t pe = pb.ensure(need);
             if (pe == hipSuccess) pe = pp.ensure(need_planes);
-            if (pe == hipSuccess) pe = pm.ensure(need_match);
+            if (pe == hipSuccess && need_match) pe = pm.ensure(need_match);
             if (pe == hipSuccess && need_ovf) pe = ov.ensure(need_ovf);
             if (pe != hipSuccess) return fail(SMX_ERR_DEVICE, "prescan buffers: %s", hipGetErrorString(pe));
         }
@@ -610,7 +604,7 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         const int grid_t = (int)std::min<uint32_t>(ptiles, (uint32_t)(P->n_cu * P->pre_blocks_t));
         const int grid_d = (int)std::min<uint32_t>(ptiles * (uint32_t)P->hp.NP, (uint32_t)(P->n_cu * P->pre_blocks_d));
         int pe = smx_launch_prescan(&P->pre, P->pre_mr, P->pre_nx, grid_t, P->pre_lds, grid_d, stream, d_windows, d_lens, n_reads,
-                                    P->hp.wstride, (unsigned *)pp.p, (unsigned *)pb.p, (unsigned *)pm.p,
+                                    P->hp.wstride, (unsigned *)pp.p, (unsigned *)pb.p, P->nitems > 0 ? (unsigned *)pm.p : nullptr,
                                     P->kev_on ? (void *)P->kev[1] : nullptr);
         if (pe != 0) return fail(SMX_ERR_DEVICE, "prescan kernel launch failed: %s", hipGetErrorString((hipError_t)pe));
         d_pre = (const unsigned *)pb.p;

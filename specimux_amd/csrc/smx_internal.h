@@ -39,11 +39,8 @@ struct DevPanel {
     const int *pbc_off, *pbc;             // per primer barcode list (global barcode indices)
     const int *bm;                        // per barcode length
     const int *pair_f, *pair_r, *pair_pool;
-    const int *pairhead;                  // NB*NB: first specimen (file order) with (b1,b2), -1
-    const int *spec_next;                 // chain in file order
-    const unsigned long long *spec_p1m, *spec_p2m;
-    const int *spec_pool;
-    const SpecRec *pairrec, *specrec;     // packed copies of the five tables above (nullptr for very large barcode sets)
+    const SpecRec *pairrec;               // NB*NB: the first specimen (file order) with (b1, b2), as a whole record; spec = -1: none
+    const SpecRec *specrec;               // per specimen: its record (next = the following specimen with the same barcode pair)
     // bit-sliced barcode scan (lean mode): all barcodes one length bs_m <= 16, k <= 7.
     // bs_re[((p * 16 + row) * 16 + code) * MBW + w] = bitmask over primer p's barcode list: barcode_rc[row] eq code
     int bs_ok, bs_m;

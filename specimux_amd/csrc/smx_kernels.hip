@@ -595,28 +595,34 @@ __device__ inline bool tied_has_global(const ReadCtx &c, int h, int gb) {
 }
 
 // Specimens.specimen_for_exact_match (databases.py:232-245): first specimen in file order.
-// With the packed tables (DevPanel::pairrec) the usual lookup is ONE 32-byte load -- the (b1, b2) cell holds the first
-// specimen's whole record -- instead of three dependent ones (head of the chain, its primer masks, its pool): the scorer
-// wave sits on a tile's critical path and every dependent global load is most of a microsecond.
+// One 32-byte load in the usual case -- the (b1, b2) cell holds the first specimen's whole record (masks, pool, next) --
+// instead of three dependent ones (head of the chain, its primer masks, its pool): the scorer wave sits on a tile's
+// critical path and every dependent global load is most of a microsecond.  The flat tables are gone from the device:
+// five fewer pointers held in (spilled) SGPRs.
 __device__ inline int specimen_exact(const DevPanel *P, int gb1, int gb2, int f, int r, int *pool_out = nullptr) {
-    if (P->pairrec) {
-        SpecRec rec = P->pairrec[(size_t)gb1 * P->NB + gb2];
-        while (rec.spec >= 0) {
-            if (((rec.p1m >> f) & 1) && ((rec.p2m >> r) & 1)) {
-                if (pool_out) *pool_out = rec.pool;
-                return rec.spec;
-            }
-            if (rec.next < 0) break;
-            rec = P->specrec[rec.next];
+    SpecRec rec = P->pairrec[(size_t)gb1 * P->NB + gb2];
+    while (rec.spec >= 0) {
+        if (((rec.p1m >> f) & 1) && ((rec.p2m >> r) & 1)) {
+            if (pool_out) *pool_out = rec.pool;
+            return rec.spec;
         }
-        return -1;
+        if (rec.next < 0) break;
+        rec = P->specrec[rec.next];
     }
-    for (int s = P->pairhead[gb1 * P->NB + gb2]; s >= 0; s = P->spec_next[s])
-        if (((P->spec_p1m[s] >> f) & 1) && ((P->spec_p2m[s] >> r) & 1)) {
-            if (pool_out) *pool_out = P->spec_pool[s];
-            return s;
-        }
     return -1;
+}
+// Specimens.specimens_for_barcodes_and_primers (databases.py): how many specimens carry (b1, b2) with these primers, and
+// the first of them in file order
+__device__ inline void specimens_for(const DevPanel *P, int gb1, int gb2, int f, int r, int &first, int &cnt) {
+    SpecRec rec = P->pairrec[(size_t)gb1 * P->NB + gb2];
+    while (rec.spec >= 0) {
+        if (((rec.p1m >> f) & 1) && ((rec.p2m >> r) & 1)) {
+            cnt++;
+            if (first < 0 || rec.spec < first) first = rec.spec;
+        }
+        if (rec.next < 0) break;
+        rec = P->specrec[rec.next];
+    }
 }
 
 // Trim extents of a candidate whose stored locations were already shifted by `cum` (Q8).
@@ -899,11 +905,7 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
             if (!(t1 && t2)) return false;
             const int g1 = global_bc(c, v.h1, a.first_tied), g2 = global_bc(c, v.h2, b.first_tied);
             int first = -1, cnt = 0;
-            for (int sp = P->pairhead[g1 * P->NB + g2]; sp >= 0; sp = P->spec_next[sp])
-                if (((P->spec_p1m[sp] >> v.f) & 1) && ((P->spec_p2m[sp] >> v.r) & 1)) {
-                    cnt++;
-                    if (first < 0 || sp < first) first = sp;
-                }
+            specimens_for(P, g1, g2, v.f, v.r, first, cnt);
             if (cnt > 0) { sample = first; rtype = cnt > 1 ? SMX_R_MULTIPLE : SMX_R_FULL; }
             else xflags = SMX_OPF_NO_SPECIMEN;
         } else {
@@ -934,13 +936,13 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
     }
     if (!lead) return true;
     const CandView v = cand_view(c, pair, o);
-    const int pool = !has_v ? -1 : (sample >= 0 ? (spool != -2 ? spool : P->spec_pool[sample]) : c.LP.pair_pool[pair]);
+    const int pool = !has_v ? -1 : (sample >= 0 ? (spool != -2 ? spool : P->specrec[sample].pool) : c.LP.pair_pool[pair]);
     emit_op(E, has_v ? &v : nullptr, pair * 2 + o, sample, rtype, pool, barcode, xflags);
     for (int e = 1; e < repeat; e++) emit_op(E, &v, pair * 2 + o, -1, SMX_R_UNKNOWN, pool, -1, 0);   // rare
     if (more1 >= 0) {   // rare
         for (int e = 0; e < 3; e++) {
             int sp = e == 0 ? more1 : (e == 1 ? more2 : more3);
-            if (sp >= 0) emit_op(E, &v, pair * 2 + o, sp, SMX_R_DEREP_FULL, P->spec_pool[sp], -1, 0);
+            if (sp >= 0) emit_op(E, &v, pair * 2 + o, sp, SMX_R_DEREP_FULL, P->specrec[sp].pool, -1, 0);
         }
     }
     return true;
@@ -970,14 +972,10 @@ __device__ inline void score_general(Emitter &E, int ori) {
                 for (int i = next_tied(c, v.h1, 0); i >= 0; i = next_tied(c, v.h1, i + 1))
                     for (int j = next_tied(c, v.h2, 0); j >= 0; j = next_tied(c, v.h2, j + 1)) {
                         int g1 = global_bc(c, v.h1, i), g2 = global_bc(c, v.h2, j);
-                        for (int s = P->pairhead[g1 * P->NB + g2]; s >= 0; s = P->spec_next[s])
-                            if (((P->spec_p1m[s] >> v.f) & 1) && ((P->spec_p2m[s] >> v.r) & 1)) {
-                                cnt++;
-                                if (first < 0 || s < first) first = s;
-                            }
+                        specimens_for(P, g1, g2, v.f, v.r, first, cnt);
                     }
-                if (cnt > 1) emit_op(E, &v, cand_id, first, SMX_R_MULTIPLE, P->spec_pool[first], -1, 0);
-                else if (cnt == 1) emit_op(E, &v, cand_id, first, SMX_R_FULL, P->spec_pool[first], -1, 0);
+                if (cnt > 1) emit_op(E, &v, cand_id, first, SMX_R_MULTIPLE, P->specrec[first].pool, -1, 0);
+                else if (cnt == 1) emit_op(E, &v, cand_id, first, SMX_R_FULL, P->specrec[first].pool, -1, 0);
                 else emit_op(E, &v, cand_id, -1, SMX_R_UNKNOWN, cand_pool, -1, SMX_OPF_NO_SPECIMEN);
             } else {
                 emit_partial_or_unknown(E, v, cand_id, cand_pool);
@@ -1019,7 +1017,7 @@ __device__ inline void score_general(Emitter &E, int ori) {
                         if (k < wkey && cand_has_specimen(c, v, spec)) { wkey = k; wid = cand_id; }
                     })
                     CandView w = cand_view(c, wid >> 1, wid & 1);
-                    emit_op(E, &w, wid, spec, SMX_R_DEREP_FULL, P->spec_pool[spec], -1, 0);
+                    emit_op(E, &w, wid, spec, SMX_R_DEREP_FULL, P->specrec[spec].pool, -1, 0);
                 }
             if (!any && !none_done) {
                 // the None group sits where its first entry appeared; it holds every best candidate
@@ -1077,26 +1075,34 @@ __device__ inline void score_general(Emitter &E, int ori) {
 // apart): 0 = per-barcode bit-vector scan only, 1 = bit-sliced, k <= 3 (padded 7-row window), 2 = bit-sliced, k 4..7,
 // 3 = variant 1 + the --trim tails extent on the lean path (<= 32 barcodes per primer).
 // CM = 1: compact mode compiled in (its own instantiation: the dense kernel's register allocation stays as it was).
+// CM = 2: the dense redo launch behind a compact one (tiles come from the overflow list); the plain dense kernel (CM = 0)
+// carries none of that state.
 template <typename PW, int NT, int BSV, int CM = 0>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
 __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
-                                                    unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist,
-                                                    unsigned *tile_counter, int use_slots,
+                                                    unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist_arg,
+                                                    unsigned *tile_counter, int use_slots_arg,
                                                     const unsigned *__restrict__ pre, uint32_t npad, DemuxAux aux) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
     const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
     const int n_pbc = P->n_pbc, NPAIR = P->NPAIR;
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
-    const int use_bs = (BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0;
-    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta, P->kidx, use_slots, P->bs_ok,
+    // The launch glue picks BSV != 0 exactly when the panel has a bit-sliced table and the launch is not in slots mode: inside
+    // those variants both are compile-time facts (no slots-mode code, none of its uniform state held in SGPRs -- the lean
+    // kernel spills hundreds of them, and every reload is a v_readlane in somebody's loop).
+    const int use_slots = BSV != 0 ? 0 : use_slots_arg;
+    const int use_bs = BSV != 0 ? 1 : 0;
+    int8_t *dbg_bdist = BSV != 0 ? nullptr : dbg_bdist_arg;
+    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta, P->kidx, use_slots, BSV != 0 ? 1 : P->bs_ok,
                                          P->cap_hits, P->cap_ents, aux.nitems);
     // compact mode (aux.nitems > 0, lean launches of many-primer panels behind the prescan): records only for the
     // alignments the prescan's match words flag; a tile with more flagged alignments than records is put on the
     // overflow list and left to the dense redo launch that follows (aux.redo)
-    constexpr bool cmode = CM != 0;
+    constexpr bool cmode = CM == 1;
+    constexpr bool redo = CM == 2;
     PW *ppeq = (PW *)(lds + T.ppeq);        // [code][primer], stride NPs
     PW *prpeq = (PW *)(lds + T.prpeq);
     unsigned *bpeq = (unsigned *)(lds + T.bpeq);   // [code][barcode], stride NBs
@@ -1137,13 +1143,13 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         if (prev == gridDim.x - 1) {
             __threadfence();
             tile_counter[0] = 0; tile_counter[2] = 0;
-            if (!aux.chain) {
+            if (!cmode) {   // (a compact launch is always followed by its redo launch: the extra-record and overflow counters stay)
                 *n_extra = atomicAdd(tile_counter + 3, 0u);
                 tile_counter[1] = 0; tile_counter[3] = 0;
             }
         }
     };
-    if (aux.redo && tile_counter[1] == 0) {   // the usual redo launch: nothing on the list (every workgroup sees the same count:
+    if (redo && tile_counter[1] == 0) {   // the usual redo launch: nothing on the list (every workgroup sees the same count:
         if (tid == 0) workgroup_done();       // it is only zeroed once all of them have passed this point)
         return;
     }
@@ -1213,10 +1219,10 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     const unsigned hcmagic = (unsigned)((0x100000000ull + (unsigned)(S >> 4) - 1) / (unsigned)((S >> 4) > 0 ? (S >> 4) : 1));   // chunk / (S/16)
     // tile -> reads.  Normal launch: tile t = reads [t R, t R + R).  Redo launch: the overflow list holds tiles of Rc reads
     // each; every one of them is cut into ceil(Rc / R) tiles of this launch.
-    const uint32_t redo_ratio = aux.redo ? (uint32_t)((aux.Rc + R - 1) / R) : 1u;
-    const uint32_t n_tiles = aux.redo ? tile_counter[1] * redo_ratio : (n_reads + R - 1) / R;
+    const uint32_t redo_ratio = redo ? (uint32_t)((aux.Rc + R - 1) / R) : 1u;
+    const uint32_t n_tiles = redo ? tile_counter[1] * redo_ratio : (n_reads + R - 1) / R;
     auto tile_span = [&](uint32_t t, uint32_t &first, int &count) {
-        if (!aux.redo) {
+        if (!redo) {
             first = t * (uint32_t)R;
             count = (int)((n_reads - first) < (uint32_t)R ? (n_reads - first) : (uint32_t)R);
         } else {
@@ -1960,31 +1966,12 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 // [all tail chunks] so that a wave is (almost always) uniform in role.  Full windows (len >= S):
                 // four LUT lookups -> one packed dword store; the head is written reversed (reverse complement).
                 const int hc = S >> 4, nhead = nrn * hc, S4 = S >> 2;
-                // four chunks per lane and pass, all their loads (window piece, read length) issued before the first is
-                // used: one memory round trip per pass instead of one per chunk (a load inside the per-chunk branch is
-                // waited for before the next one is issued; the encode waves' time is load latency)
-                constexpr int EB = 4;
-                for (int ci0 = wid; ci0 < 2 * nhead; ci0 += EB * nw) {
-                uint4 vb[EB];
-                int Lb[EB];
-#pragma unroll
-                for (int u = 0; u < EB; u++) {
-                    const int ci = ci0 + u * nw < 2 * nhead ? ci0 + u * nw : 2 * nhead - 1;
+                for (int ci = wid; ci < 2 * nhead; ci += nw) {
                     const bool tail = ci >= nhead;
                     const int k = tail ? ci - nhead : ci;
                     const int r = (int)__umulhi((unsigned)k, hcmagic), c = k - __mul24(r, hc);
-                    vb[u] = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (tail ? S : 0) + 16 * c);
-                    Lb[u] = lens[r0n + r];
-                }
-#pragma unroll
-                for (int u = 0; u < EB; u++) {
-                    const int ci = ci0 + u * nw;
-                    if (ci >= 2 * nhead) break;
-                    const bool tail = ci >= nhead;
-                    const int k = tail ? ci - nhead : ci;
-                    const int r = (int)__umulhi((unsigned)k, hcmagic), c = k - __mul24(r, hc);
-                    const uint4 v = vb[u];
-                    const int L = Lb[u];
+                    const uint4 v = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (tail ? S : 0) + 16 * c);
+                    const int L = lens[r0n + r];
                     // ACGT fast path, four bases per dword without the LUT: (ch >> 1) & 3 maps A,C,T,G -> 0,1,2,3; swapping 2 and 3
                     // gives the code, xor 3 the complement's code; one v_perm rebuilds the four letters from the codes and a
                     // compare proves that the dword held nothing but upper-case ACGT (anything else: per-byte LUT path below)
@@ -2005,7 +1992,6 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     } else {
                         encode_bytes(r, L, (tail ? S : 0) + 16 * c, v);
                     }
-                }
                 }
             } else {
                 const int chunks = stride / 16;
@@ -2159,10 +2145,15 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
     // by the last workgroup of every launch (of the last launch of a chain)
     // one instantiation per (primer word width, barcode scan variant); slots mode never uses the bit-sliced scan
     const int bsv = (use_slots || !P->bs_ok) ? 0 : (P->kidx < 4 ? (P->trim == SMX_TRIM_TAILS ? 3 : 1) : 2);
-    if (aux.nitems > 0 && use64) return (int)hipErrorInvalidValue;   // (the prescan serves primers of <= 31 nt only)
+    if ((aux.nitems > 0 || aux.redo) && use64) return (int)hipErrorInvalidValue;   // (the prescan serves primers of <= 31 nt only)
+    if (aux.nitems > 0 && !aux.chain) return (int)hipErrorInvalidValue;              // a compact launch needs its redo launch
 #define SMX_LAUNCH(PWT, BSVV)                                                                                         \
     if (aux.nitems > 0)                                                                                               \
         hipLaunchKernelGGL((smx::demux_kernel<unsigned, 256, BSVV, 1>), dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
+                       d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits, d_bdist,        \
+                       d_tile_counter, use_slots, d_pre, npad, aux);                                                  \
+    else if (aux.redo)                                                                                                \
+        hipLaunchKernelGGL((smx::demux_kernel<unsigned, 256, BSVV, 2>), dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
                        d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits, d_bdist,        \
                        d_tile_counter, use_slots, d_pre, npad, aux);                                                  \
     else                                                                                                              \
@@ -2194,8 +2185,10 @@ extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
         if (r != hipSuccess) e = r;
     }
     if (!use64) {
-        const void *cf[4] = {(const void *)smx::demux_kernel<unsigned, 256, 0, 1>, (const void *)smx::demux_kernel<unsigned, 256, 1, 1>,
-                             (const void *)smx::demux_kernel<unsigned, 256, 2, 1>, (const void *)smx::demux_kernel<unsigned, 256, 3, 1>};
+        const void *cf[8] = {(const void *)smx::demux_kernel<unsigned, 256, 0, 1>, (const void *)smx::demux_kernel<unsigned, 256, 1, 1>,
+                             (const void *)smx::demux_kernel<unsigned, 256, 2, 1>, (const void *)smx::demux_kernel<unsigned, 256, 3, 1>,
+                             (const void *)smx::demux_kernel<unsigned, 256, 0, 2>, (const void *)smx::demux_kernel<unsigned, 256, 1, 2>,
+                             (const void *)smx::demux_kernel<unsigned, 256, 2, 2>, (const void *)smx::demux_kernel<unsigned, 256, 3, 2>};
         for (const void *f : cf) {
             hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (r != hipSuccess) e = r;

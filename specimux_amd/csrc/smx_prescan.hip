@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void prescan_transpose_kernel(int S, const uin
 #ifndef SMX_PRE_WAVES
 #define SMX_PRE_WAVES 2   // waves per SIMD the DP kernel's register allocation aims at
 #endif
-template <int MR, int NX>
+template <int MR, int NX, int MT>
 __global__ __launch_bounds__(64, SMX_PRE_WAVES) void prescan_dp_kernel(PreDesc D, const unsigned *__restrict__ gplanes,
                                                            unsigned *__restrict__ out, unsigned *__restrict__ match,
                                                            uint32_t ntiles) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64, SMX_PRE_WAVES) void prescan_dp_kernel(PreDesc D
         const int p = (int)(wi - tile * (uint32_t)D.NP);
         const int g = lane >> 1, X = lane & 1;
         // tile-major output: the CH x 2 NP words of a read sit within its tile's 4 * 2 NP * CH KB
-        prescan_dp<MR, NX>(gplanes + (size_t)tile * CH * 8 * 64 * 4, scratch, lane, CH, D, p,
+        prescan_dp<MR, NX, MT>(gplanes + (size_t)tile * CH * 8 * 64 * 4, scratch, lane, CH, D, p,
                            out + ((size_t)tile * (2 * D.NP) + (size_t)(2 * p + X)) * CH * PRE_TILE + (uint32_t)g * 32u, PRE_TILE,
                            match + ((size_t)tile * (2 * D.NP) + (size_t)(2 * p + X)) * PRE_G + (uint32_t)g);
     }
@@ -135,14 +135,14 @@ extern "C" size_t smx_prescan_lds_bytes(int S) {   // the transpose kernel's sta
 
 static const void *prescan_fn(int mr, int nx) {
     const int mrv = mr <= 24 ? 24 : 31, nxv = nx > 0 ? 4 : 0;
-#define X(MRV, NXV) if (mrv == MRV && nxv == NXV) return (const void *)smx::prescan_dp_kernel<MRV, NXV>;
+#define X(MRV, NXV) if (mrv == MRV && nxv == NXV) return (const void *)smx::prescan_dp_kernel<MRV, NXV, 1>;
     SMX_PRE_VARIANTS(X)
 #undef X
     return nullptr;
 }
 
 // mr = longest primer of the panel, nx = largest number of degenerate-letter symbols of one primer;
-// grid_t / grid_d = resident workgroups of the two kernels (the caller sizes them)
+// grid_t / grid_d = resident workgroups of the two kernels (the caller sizes them); d_match = nullptr: no match words
 extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int grid_t, size_t lds_t, int grid_d, void *stream,
                                   const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride,
                                   unsigned *d_planes, unsigned *d_out, unsigned *d_match, void *ev_mid) {
@@ -156,8 +156,12 @@ extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int gri
     if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);   // diagnostic: boundary between the two kernels
     const int mrv = mr <= 24 ? 24 : 31, nxv = nx > 0 ? 4 : 0;
 #define X(MRV, NXV)                                                                                            \
-    if (mrv == MRV && nxv == NXV)                                                                              \
-        hipLaunchKernelGGL((smx::prescan_dp_kernel<MRV, NXV>), dim3(grid_d), dim3(64), 0, s, *D, d_planes, d_out, d_match, ntiles);
+    if (mrv == MRV && nxv == NXV) {                                                                            \
+        if (d_match)                                                                                           \
+            hipLaunchKernelGGL((smx::prescan_dp_kernel<MRV, NXV, 1>), dim3(grid_d), dim3(64), 0, s, *D, d_planes, d_out, d_match, ntiles); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((smx::prescan_dp_kernel<MRV, NXV, 0>), dim3(grid_d), dim3(64), 0, s, *D, d_planes, d_out, d_match, ntiles); \
+    }
     SMX_PRE_VARIANTS(X)
 #undef X
     return (int)hipGetLastError();

@@ -218,7 +218,9 @@ SMX_HD void prescan_write_occ(unsigned *sc, unsigned b0, unsigned b1, const unsi
 // read the all-ones word of scratch row PRE_MAXSYM and start with a zero vertical delta, so every delta on them stays 0 and
 // the first pattern row sees the free top row of the HW alignment (straight-line code, no per-row branch; jumping into
 // the unrolled rows instead cost hundreds of register copies per column).
-template <int MR, int NX>
+// MT = 1: also count the new minima per read and write the match word (the compact demux tiles read it; other panels
+// skip the nine bit-ops per column).
+template <int MR, int NX, int MT = 1>
 SMX_HD void prescan_dp(const unsigned *gpl, unsigned *scratch, int lane, int CH, const PreDesc &D, int p, unsigned *wout,
                        size_t cstride, unsigned *mout) {
     const int m = D.m[p], skip = MR - m;
@@ -325,12 +327,14 @@ SMX_HD void prescan_dp(const unsigned *gpl, unsigned *scratch, int lane, int CH,
             tt = ~g3 & bw; g3 ^= bw; bw = tt;
             g4 ^= bw;
             zero = ~(g0 | g1 | g2 | g3 | g4);
-            cy = lt;
-            tt = n0 & cy; n0 ^= cy; cy = tt;
-            tt = n1 & cy; n1 ^= cy; cy = tt;
-            tt = n2 & cy; n2 ^= cy; cy = tt;
-            tt = n3 & cy; n3 ^= cy; cy = tt;
-            n4 ^= cy;
+            if (MT) {
+                cy = lt;
+                tt = n0 & cy; n0 ^= cy; cy = tt;
+                tt = n1 & cy; n1 ^= cy; cy = tt;
+                tt = n2 & cy; n2 ^= cy; cy = tt;
+                tt = n3 & cy; n3 ^= cy; cy = tt;
+                n4 ^= cy;
+            }
             fl[t] = lt;
             fl[16 + t] = zero;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -349,7 +353,7 @@ SMX_HD void prescan_dp(const unsigned *gpl, unsigned *scratch, int lane, int CH,
     // match word: bit r = read r reaches distance <= k somewhere in the S columns  <=>  new minima >= m - k (bit-sliced
     // compare against the uniform threshold).  For a read shorter than the window this is a superset of "matches within
     // its own columns" (a minimum over fewer columns is not smaller): the consumer uses it to skip alignments only.
-    {
+    if (MT) {
         const unsigned thr = (unsigned)(m - (int)D.k[p]);
         const unsigned nb[5] = {n0, n1, n2, n3, n4};
         unsigned gt = 0u, eq = ~0u;

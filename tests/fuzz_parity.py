@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1200)
     ap.add_argument("--trim", default=None, help="force this trim mode onto every flag set (e.g. tails)")
     ap.add_argument("--index-k", type=int, default=None, help="force this index edit distance onto every flag set")
+    ap.add_argument("--panel", default=None, choices=["c1", "c2", "c3"], help="this panel only (default: all three in rotation)")
     a = ap.parse_args()
     from specimux_amd import synth
     flag_sets = [dict(), dict(trim="tails"), dict(trim="primers"), dict(dereplicate="none"), dict(disable_prefilter=True),
@@ -46,7 +47,7 @@ def main():
     t0 = time.time()
     checked = 0
     for seed, (fi, flags) in itertools.product(range(a.seeds), enumerate(flag_sets)):
-        name = ("c2", "c3", "c1")[(seed + fi) % 3]
+        name = a.panel or ("c2", "c3", "c1")[(seed + fi) % 3]
         pan, (pf, sf) = panels[name], files[name]
         flags = dict(flags)
         gen = {k: flags.pop(k) for k in ("error_rate", "n_frac") if k in flags}   # generator-only knobs

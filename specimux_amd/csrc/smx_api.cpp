@@ -621,8 +621,17 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         const int cgrid = (int)std::min<uint32_t>(ctiles, (uint32_t)(P->n_cu * P->blocks_per_cu_c));
         e = smx_launch_demux(&P->hp, P->use64, P->Rc, cgrid, P->lds_c, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
                              extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, 0, d_pre, npad, &ax);
+        if (e == 0 && getenv("SMX_DEBUG_OVERFLOW")) {   // diagnostic: how many compact tiles went on the overflow list
+            unsigned n_ovf = 0;
+            (void)hipMemcpyAsync(&n_ovf, tc + 1, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream);
+            (void)hipStreamSynchronize((hipStream_t)stream);
+            fprintf(stderr, "[smx] compact launch: %u of %u tiles left to the redo launch\n", n_ovf, ctiles);
+        }
         if (e == 0) {
+            // the redo launch usually finds an empty list: one workgroup per CU is enough to start with (its workgroups
+            // loop over the list), and an empty 256-workgroup launch costs less than an empty full-residency one
             smx::DemuxAux rx = {nullptr, (unsigned *)P->ovf[slot].p, 0, 1, P->Rc, 0};
+            grid = std::min(grid, P->n_cu);
             e = smx_launch_demux(&P->hp, P->use64, R, grid, lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
                                  extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, 0, d_pre, npad, &rx);
         }

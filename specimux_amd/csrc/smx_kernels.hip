@@ -1082,21 +1082,16 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
-                                                    unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist_arg,
-                                                    unsigned *tile_counter, int use_slots_arg,
+                                                    unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist,
+                                                    unsigned *tile_counter, int use_slots,
                                                     const unsigned *__restrict__ pre, uint32_t npad, DemuxAux aux) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
     const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
     const int n_pbc = P->n_pbc, NPAIR = P->NPAIR;
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
-    // The launch glue picks BSV != 0 exactly when the panel has a bit-sliced table and the launch is not in slots mode: inside
-    // those variants both are compile-time facts (no slots-mode code, none of its uniform state held in SGPRs -- the lean
-    // kernel spills hundreds of them, and every reload is a v_readlane in somebody's loop).
-    const int use_slots = BSV != 0 ? 0 : use_slots_arg;
-    const int use_bs = BSV != 0 ? 1 : 0;
-    int8_t *dbg_bdist = BSV != 0 ? nullptr : dbg_bdist_arg;
-    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta, P->kidx, use_slots, BSV != 0 ? 1 : P->bs_ok,
+    const int use_bs = (BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0;
+    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta, P->kidx, use_slots, P->bs_ok,
                                          P->cap_hits, P->cap_ents, aux.nitems);
     // compact mode (aux.nitems > 0, lean launches of many-primer panels behind the prescan): records only for the
     // alignments the prescan's match words flag; a tile with more flagged alignments than records is put on the

@@ -1077,7 +1077,11 @@ __device__ inline void score_general(Emitter &E, int ori) {
 // CM = 1: compact mode compiled in (its own instantiation: the dense kernel's register allocation stays as it was).
 // CM = 2: the dense redo launch behind a compact one (tiles come from the overflow list); the plain dense kernel (CM = 0)
 // carries none of that state.
-template <typename PW, int NT, int BSV, int CM = 0>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
+// SP = 1: the reference's default flags as compile-time facts -- search_len 80, index edit distance 3, at most 32
+// barcodes per primer (one tie-mask word), no primer start scans (--trim barcodes / none).  The kernel holds > 100 uniform
+// values and spills hundreds of SGPRs; every dimension that is a constant is one fewer of them, and the loops over mask
+// words / distance levels / window chunks get constant trip counts.
+template <typename PW, int NT, int BSV, int CM = 0, int SP = 0>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
 __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
@@ -1087,11 +1091,13 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                                                     const unsigned *__restrict__ pre, uint32_t npad, DemuxAux aux) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
-    const int NP = P->NP, NB = P->NB, S = P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
+    constexpr bool sp = SP != 0;
+    const int NP = P->NP, NB = P->NB, S = sp ? 80 : P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
+    const int need_starts = sp ? 0 : P->need_starts;
     const int n_pbc = P->n_pbc, NPAIR = P->NPAIR;
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
     const int use_bs = (BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0;
-    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, P->need_starts, npmeta, P->kidx, use_slots, P->bs_ok,
+    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, need_starts, npmeta, sp ? 3 : P->kidx, use_slots, P->bs_ok,
                                          P->cap_hits, P->cap_ents, aux.nitems);
     // compact mode (aux.nitems > 0, lean launches of many-primer panels behind the prescan): records only for the
     // alignments the prescan's match words flag; a tile with more flagged alignments than records is put on the
@@ -1149,13 +1155,13 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         return;
     }
     constexpr int PWBITS = (int)sizeof(PW) * 8;
-    const int CS = T.CS, NPs = T.NPs, NBs = T.NBs, lNPs = T.lNPs, lNBs = T.lNBs, G = T.G, logG = T.logG, MBW = T.MBW;
+    const int CS = T.CS, NPs = T.NPs, NBs = T.NBs, lNPs = T.lNPs, lNBs = T.lNBs, G = T.G, logG = T.logG, MBW = sp ? 1 : T.MBW;
 
     // ---- phase 0: stage the panel (transposed: consecutive lanes = consecutive patterns hit distinct banks)
     for (int i = tid; i < NP * 16; i += NT) {
         int p = i >> 4, c = i & 15;
         ppeq[c * NPs + p] = (PW)P->ppeq[i] << (PWBITS - P->pm[p]);   // left-aligned: row m-1 is the top bit
-        if (P->need_starts) prpeq[c * NPs + p] = (PW)P->prpeq[i];
+        if (need_starts) prpeq[c * NPs + p] = (PW)P->prpeq[i];
     }
     if (!use_bs)
         for (int i = tid; i < NB * 16; i += NT) bpeq[(i & 15) * NBs + (i >> 4)] = P->bpeq[i];
@@ -1204,7 +1210,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     __syncthreads();
 
     const int stride = P->wstride;
-    const int kidx = P->kidx, pfmin = P->pfmin;
+    const int kidx = sp ? 3 : P->kidx, pfmin = P->pfmin;
     // Integer division by the (uniform, runtime) item strides: a generic `x / H` is a ~30-instruction sequence on the
     // VALU and sits in every per-item loop.  H is a power of two for 1, 2, 4, 8 ... primers (shift); otherwise one
     // v_mul_hi with ceil(2^32 / H), exact for x < 2^32 / H (items are < 2^16).
@@ -1382,7 +1388,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 omatch = b2 <= k;
             }
             int fs_j = jstar;
-            if (matched && P->need_starts) {
+            if (matched && need_starts) {
                 // edlib's start rule: SHW of the reversed pattern over the reversed target prefix,
                 // LAST optimal position = smallest start
                 const PW *rpeq = prpeq + p;
@@ -2126,40 +2132,58 @@ __global__ __launch_bounds__(64) void align_batch_kernel(const unsigned long lon
 
 // ------------------------------------------------------------------------------------------------
 // launch glue used by smx_api.cpp
+namespace {
+// one instantiation per (primer word width, barcode scan variant, compact / redo mode, default-flags specialisation)
+const void *demux_fn(int use64, int bsv, int cm, int sp) {
+    if (use64) {
+        switch (bsv) {
+            case 0: return (const void *)smx::demux_kernel<unsigned long long, 256, 0>;
+            case 1: return (const void *)smx::demux_kernel<unsigned long long, 256, 1>;
+            case 2: return (const void *)smx::demux_kernel<unsigned long long, 256, 2>;
+            default: return (const void *)smx::demux_kernel<unsigned long long, 256, 3>;
+        }
+    }
+#define SMX_FN(B, C, S_) (const void *)smx::demux_kernel<unsigned, 256, B, C, S_>
+    if (sp && bsv == 1) return cm == 1 ? SMX_FN(1, 1, 1) : SMX_FN(1, 0, 1);
+    switch (bsv * 3 + cm) {
+        case 0: return SMX_FN(0, 0, 0); case 1: return SMX_FN(0, 1, 0); case 2: return SMX_FN(0, 2, 0);
+        case 3: return SMX_FN(1, 0, 0); case 4: return SMX_FN(1, 1, 0); case 5: return SMX_FN(1, 2, 0);
+        case 6: return SMX_FN(2, 0, 0); case 7: return SMX_FN(2, 1, 0); case 8: return SMX_FN(2, 2, 0);
+        case 9: return SMX_FN(3, 0, 0); case 10: return SMX_FN(3, 1, 0); default: return SMX_FN(3, 2, 0);
+    }
+#undef SMX_FN
+}
+int demux_bsv(const smx::DevPanel *P, int use_slots) {
+    return (use_slots || !P->bs_ok) ? 0 : (P->kidx < 4 ? (P->trim == SMX_TRIM_TAILS ? 3 : 1) : 2);
+}
+// the default-flags specialisation applies to the k <= 3 lean kernel (not its tails variant, not the redo launch)
+int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm) {
+    return (!use64 && bsv == 1 && cm != 2 && P->S == 80 && P->kidx == 3 && P->maxB <= 32 && !P->need_starts && !getenv("SMX_NO_SPECIALISE")) ? 1 : 0;
+}
+}  // namespace
+
 extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t lds_bytes, void *stream,
                                 const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops,
                                 smx_op *d_extra, uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts,
                                 smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter, int use_slots,
                                 const unsigned *d_pre, uint32_t npad, const smx::DemuxAux *aux_in) {
-    hipStream_t s = (hipStream_t)stream;
     smx::DemuxAux aux = {nullptr, nullptr, 0, 0, 0, 0};
     if (aux_in) aux = *aux_in;
     if (aux.nitems > 0 && (use_slots || !d_pre || !aux.match || !aux.ovf_list || aux.nitems > 256)) return (int)hipErrorInvalidValue;
     if (aux.redo && (!aux.ovf_list || aux.Rc < 1)) return (int)hipErrorInvalidValue;
-    // d_tile_counter = {tile queue head, overflow tiles, finished workgroups, extra records}: zero at allocation, re-armed
-    // by the last workgroup of every launch (of the last launch of a chain)
-    // one instantiation per (primer word width, barcode scan variant); slots mode never uses the bit-sliced scan
-    const int bsv = (use_slots || !P->bs_ok) ? 0 : (P->kidx < 4 ? (P->trim == SMX_TRIM_TAILS ? 3 : 1) : 2);
     if ((aux.nitems > 0 || aux.redo) && use64) return (int)hipErrorInvalidValue;   // (the prescan serves primers of <= 31 nt only)
     if (aux.nitems > 0 && !aux.chain) return (int)hipErrorInvalidValue;              // a compact launch needs its redo launch
-#define SMX_LAUNCH(PWT, BSVV)                                                                                         \
-    if (aux.nitems > 0)                                                                                               \
-        hipLaunchKernelGGL((smx::demux_kernel<unsigned, 256, BSVV, 1>), dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
-                       d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits, d_bdist,        \
-                       d_tile_counter, use_slots, d_pre, npad, aux);                                                  \
-    else if (aux.redo)                                                                                                \
-        hipLaunchKernelGGL((smx::demux_kernel<unsigned, 256, BSVV, 2>), dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
-                       d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits, d_bdist,        \
-                       d_tile_counter, use_slots, d_pre, npad, aux);                                                  \
-    else                                                                                                              \
-    hipLaunchKernelGGL((smx::demux_kernel<PWT, 256, BSVV>), dim3(grid), dim3(256), lds_bytes, s, *P, d_windows, d_lens, n_reads, R, \
-                       d_ops, d_extra, extra_cap, d_n_extra, (unsigned long long *)d_counts, d_hits, d_bdist,        \
-                       d_tile_counter, use_slots, d_pre, npad, aux)
     if (R > 64) return (int)hipErrorInvalidValue;
-    if (use64) { if (bsv == 0) SMX_LAUNCH(unsigned long long, 0); else if (bsv == 1) SMX_LAUNCH(unsigned long long, 1); else if (bsv == 2) SMX_LAUNCH(unsigned long long, 2); else SMX_LAUNCH(unsigned long long, 3); }
-    else { if (bsv == 0) SMX_LAUNCH(unsigned, 0); else if (bsv == 1) SMX_LAUNCH(unsigned, 1); else if (bsv == 2) SMX_LAUNCH(unsigned, 2); else SMX_LAUNCH(unsigned, 3); }
-#undef SMX_LAUNCH
-    return (int)hipGetLastError();
+    // d_tile_counter = {tile queue head, overflow tiles, finished workgroups, extra records}: zero at allocation, re-armed
+    // by the last workgroup of every launch (of the last launch of a chain).  Slots mode never uses the bit-sliced scan.
+    const int bsv = demux_bsv(P, use_slots), cm = aux.nitems > 0 ? 1 : (aux.redo ? 2 : 0);
+    const void *fn = demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm));
+    smx::DevPanel pv = *P;
+    unsigned long long *counts = (unsigned long long *)d_counts;
+    void *args[] = {&pv, &d_windows, &d_lens, &n_reads, &R, &d_ops, &d_extra, &extra_cap, &d_n_extra, &counts, &d_hits, &d_bdist,
+                    &d_tile_counter, &use_slots, &d_pre, &npad, &aux};
+    hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(256), args, lds_bytes, (hipStream_t)stream);
+    return (int)(e != hipSuccess ? e : hipGetLastError());
 }
 
 extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta,
@@ -2170,41 +2194,20 @@ extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, i
 
 extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
     hipError_t e = hipSuccess;
-    const void *fns[4] = {
-        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 0> : (const void *)smx::demux_kernel<unsigned, 256, 0>,
-        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 1> : (const void *)smx::demux_kernel<unsigned, 256, 1>,
-        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 2> : (const void *)smx::demux_kernel<unsigned, 256, 2>,
-        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 3> : (const void *)smx::demux_kernel<unsigned, 256, 3>};
-    for (const void *f : fns) {
-        hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (r != hipSuccess) e = r;
-    }
-    if (!use64) {
-        const void *cf[8] = {(const void *)smx::demux_kernel<unsigned, 256, 0, 1>, (const void *)smx::demux_kernel<unsigned, 256, 1, 1>,
-                             (const void *)smx::demux_kernel<unsigned, 256, 2, 1>, (const void *)smx::demux_kernel<unsigned, 256, 3, 1>,
-                             (const void *)smx::demux_kernel<unsigned, 256, 0, 2>, (const void *)smx::demux_kernel<unsigned, 256, 1, 2>,
-                             (const void *)smx::demux_kernel<unsigned, 256, 2, 2>, (const void *)smx::demux_kernel<unsigned, 256, 3, 2>};
-        for (const void *f : cf) {
-            hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-            if (r != hipSuccess) e = r;
-        }
-    }
+    for (int bsv = 0; bsv < 4; bsv++)
+        for (int cm = 0; cm < (use64 ? 1 : 3); cm++)
+            for (int sp = 0; sp < (use64 ? 1 : 2); sp++) {
+                if (sp && (bsv != 1 || cm == 2)) continue;
+                hipError_t r = hipFuncSetAttribute(demux_fn(use64, bsv, cm, sp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+                if (r != hipSuccess) e = r;
+            }
     return (int)e;
 }
 
-extern "C" int smx_query_occupancy_compact(int bsv, size_t lds_bytes, int *blocks_per_cu) {
-    const void *cf[4] = {(const void *)smx::demux_kernel<unsigned, 256, 0, 1>, (const void *)smx::demux_kernel<unsigned, 256, 1, 1>,
-                         (const void *)smx::demux_kernel<unsigned, 256, 2, 1>, (const void *)smx::demux_kernel<unsigned, 256, 3, 1>};
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, cf[bsv < 0 || bsv > 3 ? 0 : bsv], 256, lds_bytes);
-}
-
-extern "C" int smx_query_occupancy(int use64, int bsv, size_t lds_bytes, int *blocks_per_cu) {
-    const void *fns[4] = {
-        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 0> : (const void *)smx::demux_kernel<unsigned, 256, 0>,
-        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 1> : (const void *)smx::demux_kernel<unsigned, 256, 1>,
-        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 2> : (const void *)smx::demux_kernel<unsigned, 256, 2>,
-        use64 ? (const void *)smx::demux_kernel<unsigned long long, 256, 3> : (const void *)smx::demux_kernel<unsigned, 256, 3>};
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fns[bsv < 0 || bsv > 3 ? 0 : bsv], 256, lds_bytes);
+// resident workgroups per CU of the kernel a launch with these parameters would use (cm: 0 dense, 1 compact, 2 redo)
+extern "C" int smx_query_occupancy(const smx::DevPanel *P, int use64, int use_slots, int cm, size_t lds_bytes, int *blocks_per_cu) {
+    const int bsv = demux_bsv(P, use_slots);
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm)), 256, lds_bytes);
 }
 
 extern "C" int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,

@@ -507,6 +507,7 @@ struct ReadCtx {
     const unsigned *tiem;      // the records' MBW tie bitmasks each (barcodes at the best distance)
     const unsigned short *hmap;   // compact mode: this read's alignment -> record; nullptr: record = alignment
     const unsigned long long *hcand;   // per alignment: bitmask of the candidates it belongs to; nullptr: look at every candidate
+    int trim, derep;              // the panel's --trim / --dereplicate (compile-time constants in the default-flags kernel)
     unsigned long long pm;        // this read's alignments with a primer match (bit h)
     unsigned long long live;      // candidates (pair * 2 + orientation) worth looking at: one of their alignments matched, and
                                   // the orientation is allowed; all ones when there is no candidate table (hcand == nullptr)
@@ -637,14 +638,14 @@ __device__ inline void cand_extent(const ReadCtx &c, const CandView &v, int cum,
     if (v.p1) { a_end = (int)a.jstar - c.g.j_lo + c.g.shift; a_start = (int)a.fs_j - c.g.j_lo + c.g.shift; }
     if (v.p2) { b_end = (int)b.jstar - c.g.j_lo + c.g.shift; b_start = (int)b.fs_j - c.g.j_lo + c.g.shift; }
     s = 0; e = L;
-    if (P->trim == SMX_TRIM_BARCODES) {
+    if (c.trim == SMX_TRIM_BARCODES) {
         if (v.p1) s = (L - a_end - 1) - cum;
         if (v.p2) e = (b_end + 1) - cum;
-    } else if (P->trim == SMX_TRIM_PRIMERS || P->trim == SMX_TRIM_TAILS) {
+    } else if (c.trim == SMX_TRIM_PRIMERS || c.trim == SMX_TRIM_TAILS) {
         int ps = 0, pe = L;
         if (v.p1) ps = (L - a_start - 1) + 1 - cum;
         if (v.p2) pe = b_start - cum;
-        if (P->trim == SMX_TRIM_PRIMERS) { s = ps; e = pe; }
+        if (c.trim == SMX_TRIM_PRIMERS) { s = ps; e = pe; }
         else {
             if (v.b1) s = (L - a.tail_end - 1) - cum;
             else { s = ps - P->bmax; if (s < 0) s = 0; }
@@ -673,7 +674,6 @@ struct Emitter {
 __device__ inline void emit_op(Emitter &E, const CandView *v, int cand_id, int sample, int rtype, int pool,
                                int barcode, unsigned xflags) {
     const ReadCtx &c = *E.c;
-    const DevPanel *P = c.P;
     smx_op op;
     op.read = E.read;
     op.n_ops = 0;
@@ -690,7 +690,7 @@ __device__ inline void emit_op(Emitter &E, const CandView *v, int cand_id, int s
         op.p1 = op.p2 = -1;
     }
     bool fallback = false;
-    if (P->trim != SMX_TRIM_NONE) {
+    if (c.trim != SMX_TRIM_NONE) {
         if (v) {
             int cum = 0;   // Q8: the same CandidateMatch emitted earlier already had its locations shifted
             int nlog = E.n < SMX_MAX_EMIT ? E.n : SMX_MAX_EMIT;
@@ -704,7 +704,7 @@ __device__ inline void emit_op(Emitter &E, const CandView *v, int cand_id, int s
     }
     if (E.n < SMX_MAX_EMIT)
         E.emitlog[E.n] = ((unsigned)(cand_id & 0xFF) << 24) |
-                         (unsigned)(((v && P->trim != SMX_TRIM_NONE && !fallback) ? s : 0) + 0x800000);
+                         (unsigned)(((v && c.trim != SMX_TRIM_NONE && !fallback) ? s : 0) + 0x800000);
     op.trim_start = s;
     op.trim_end = e;
     if (fallback) {
@@ -838,7 +838,7 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
         // several primer-only candidates (typically both orientations of one pair): no barcode logic involved.
         // dereplicate=best -> dereplicate_unknown_matches: stable minimum of (-primer_count, primer_dist, file index);
         // dereplicate=none -> every best candidate is written as UNKNOWN (demultiplex.py:181-197, :480-538): general path
-        if (P->derep == SMX_DEREP_NONE) return sub != 0;
+        if (c.derep == SMX_DEREP_NONE) return sub != 0;
         int wkey = 0x7FFFFFFF, wci = 0x7FFF;
         for (int ci = sub; ci < ncand; ci += G) {
             const int pr = ci >> 1, oo = ci & 1;
@@ -860,7 +860,7 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
         // of them has a single untied barcode and it is the same (direction, barcode) for all, there is one group and its
         // winner -- stable minimum of key_partial -- is the one record.  Anything else: the general scorer.
         if (!lead) return true;
-        if (P->derep != SMX_DEREP_BEST) return false;
+        if (c.derep != SMX_DEREP_BEST) return false;
         int gdir = -1, ggb = -1, wkey = 0x7FFFFFFF, wci = -1;
         for (int ci = 0; ci < ncand; ci++) {
             if (!((live >> ci) & 1ull)) continue;
@@ -894,12 +894,12 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
                 // tied barcodes on the one end that has any: dereplicate_partial_matches makes one group per tied barcode,
                 // each with this candidate as its only member, and resolve_specimen turns each into UNKNOWN (the barcode is
                 // ambiguous): ntied identical records
-                if (P->derep != SMX_DEREP_BEST) return false;
+                if (c.derep != SMX_DEREP_BEST) return false;
                 repeat = v.b1 ? a.ntied : b.ntied;
             }
             else if (v.b1 && !v.b2) { rtype = SMX_R_PARTIAL_FWD; barcode = global_bc(c, v.h1, a.first_tied); }
             else if (v.b2 && !v.b1) { rtype = SMX_R_PARTIAL_REV; barcode = global_bc(c, v.h2, b.first_tied); }
-        } else if (P->derep != SMX_DEREP_BEST) {
+        } else if (c.derep != SMX_DEREP_BEST) {
             // --dereplicate none: resolve_specimen's full branch (demultiplex.py:555-575) for untied barcodes --
             // specimens_for_barcodes_and_primers in file order: one -> FULL_MATCH, several -> the first + MULTIPLE
             if (!(t1 && t2)) return false;
@@ -965,7 +965,7 @@ __device__ inline void score_general(Emitter &E, int ori) {
         emit_op(E, nullptr, 0, -1, SMX_R_UNKNOWN, -1, -1, 0);
         return;
     }
-    if (P->derep == SMX_DEREP_NONE) {   // demultiplex.py:181-197
+    if (c.derep == SMX_DEREP_NONE) {   // demultiplex.py:181-197
         FOR_BEST_CANDS(c, ori, best, {
             if (best == 5) {   // resolve_specimen full branch (:555-575): specimens_for_barcodes_and_primers
                 int first = -1, cnt = 0;
@@ -1077,13 +1077,14 @@ __device__ inline void score_general(Emitter &E, int ori) {
 // CM = 1: compact mode compiled in (its own instantiation: the dense kernel's register allocation stays as it was).
 // CM = 2: the dense redo launch behind a compact one (tiles come from the overflow list); the plain dense kernel (CM = 0)
 // carries none of that state.
-// SP = 1: the reference's default flags as compile-time facts -- search_len 80, index edit distance 3, at most 32
-// barcodes per primer (one tie-mask word), no primer start scans (--trim barcodes / none).  The kernel holds > 100 uniform
+// SP = 1: the reference's default flags as compile-time facts -- search_len 80, index edit distance 3, --trim barcodes (no
+// primer start scans), --dereplicate best, pre-orientation on, no length filter -- and at most 32 barcodes per primer (one
+// tie-mask word).  The kernel holds > 100 uniform
 // values and spills hundreds of SGPRs; every dimension that is a constant is one fewer of them, and the loops over mask
 // words / distance levels / window chunks get constant trip counts.
 template <typename PW, int NT, int BSV, int CM = 0, int SP = 0>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
 __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
-                                                    const int32_t *__restrict__ lens, uint32_t n_reads, int R,
+                                                    const int32_t *__restrict__ lens, uint32_t n_reads, int R_arg,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
                                                     unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist,
@@ -1092,6 +1093,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
     constexpr bool sp = SP != 0;
+    const int R = sp ? 64 : R_arg;   // (the specialised kernel is only launched with 64-read tiles)
     const int NP = P->NP, NB = P->NB, S = sp ? 80 : P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
     const int need_starts = sp ? 0 : P->need_starts;
     const int n_pbc = P->n_pbc, NPAIR = P->NPAIR;
@@ -1211,6 +1213,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
 
     const int stride = P->wstride;
     const int kidx = sp ? 3 : P->kidx, pfmin = P->pfmin;
+    const int preorient = sp ? 1 : P->preorient, minlen = sp ? -1 : P->minlen, maxlen = sp ? -1 : P->maxlen;
     // Integer division by the (uniform, runtime) item strides: a generic `x / H` is a ~30-instruction sequence on the
     // VALU and sits in every per-item loop.  H is a power of two for 1, 2, 4, 8 ... primers (shift); otherwise one
     // v_mul_hi with ceil(2^32 / H), exact for x < 2^32 / H (items are < 2^16).
@@ -1483,8 +1486,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             int L = lensC[r];
             int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
             int ori = 3;   // bit0: as-read candidates allowed, bit1: reverse-complement candidates allowed
-            if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
-            bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
+            if (preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
+            bool filtered = (minlen != -1 && L < minlen) || (maxlen != -1 && L > maxlen);
             int dir = LP.pdir[p];
             bool in_fwd = (dir == 0) ? (X == 0) : (X == 1);   // used by as-read candidates
             bool needed = !filtered && ((in_fwd && (ori & 1)) || (!in_fwd && (ori & 2)));
@@ -1885,7 +1888,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             const int r = tid >> lG, sub = tid & (G - 1);
             if (r < nr) {
                 int L = lensC[r];
-                bool filtered = (P->minlen != -1 && L < P->minlen) || (P->maxlen != -1 && L > P->maxlen);
+                bool filtered = (minlen != -1 && L < minlen) || (maxlen != -1 && L > maxlen);
                 const unsigned long long pm_r = pmask[r];   // (the lanes sharing a read sit in one wave: all have read it
                 if (cfilt && sub == 0) pmask[r] = 0ull;     //  when the lead lane clears it for the next tile)
                 if (sub == 0) atomicAdd(&aggr[0], 1);
@@ -1901,6 +1904,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 } else {
                     ReadCtx c;
                     c.P = P; c.LP = LP; c.MBW = MBW; c.L = L; c.S = S;
+                    c.trim = sp ? (int)SMX_TRIM_BARCODES : P->trim; c.derep = sp ? (int)SMX_DEREP_BEST : P->derep;
                     if (cmode) { c.hits = hits; c.tiem = tiem; c.hmap = hmap + r * H; }
                     else { c.hits = hits + r * H; c.tiem = tiem + r * H * MBW; c.hmap = nullptr; }
                     c.hcand = cfilt ? hcand : nullptr;
@@ -1908,7 +1912,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     c.g = end_geom(L, S);
                     int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
                     int ori = 3;
-                    if (P->preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
+                    if (preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
                     c.set_live(ori);
                     Emitter E;
                     E.c = &c; E.primary = opsL + r; E.extra = extra; E.extra_cap = extra_cap;
@@ -2156,9 +2160,12 @@ const void *demux_fn(int use64, int bsv, int cm, int sp) {
 int demux_bsv(const smx::DevPanel *P, int use_slots) {
     return (use_slots || !P->bs_ok) ? 0 : (P->kidx < 4 ? (P->trim == SMX_TRIM_TAILS ? 3 : 1) : 2);
 }
-// the default-flags specialisation applies to the k <= 3 lean kernel (not its tails variant, not the redo launch)
-int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm) {
-    return (!use64 && bsv == 1 && cm != 2 && P->S == 80 && P->kidx == 3 && P->maxB <= 32 && !P->need_starts && !getenv("SMX_NO_SPECIALISE")) ? 1 : 0;
+// the default-flags specialisation applies to the k <= 3 lean kernel (not its tails variant, not the redo launch) with
+// 64-read tiles
+int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm, int R) {
+    return (!use64 && bsv == 1 && cm != 2 && R == 64 && P->S == 80 && P->kidx == 3 && P->maxB <= 32 && !P->need_starts &&
+            P->trim == SMX_TRIM_BARCODES && P->derep == SMX_DEREP_BEST && P->preorient && P->minlen == -1 && P->maxlen == -1 &&
+            !getenv("SMX_NO_SPECIALISE")) ? 1 : 0;
 }
 }  // namespace
 
@@ -2177,7 +2184,7 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
     // d_tile_counter = {tile queue head, overflow tiles, finished workgroups, extra records}: zero at allocation, re-armed
     // by the last workgroup of every launch (of the last launch of a chain).  Slots mode never uses the bit-sliced scan.
     const int bsv = demux_bsv(P, use_slots), cm = aux.nitems > 0 ? 1 : (aux.redo ? 2 : 0);
-    const void *fn = demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm));
+    const void *fn = demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm, R));
     smx::DevPanel pv = *P;
     unsigned long long *counts = (unsigned long long *)d_counts;
     void *args[] = {&pv, &d_windows, &d_lens, &n_reads, &R, &d_ops, &d_extra, &extra_cap, &d_n_extra, &counts, &d_hits, &d_bdist,
@@ -2205,9 +2212,9 @@ extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
 }
 
 // resident workgroups per CU of the kernel a launch with these parameters would use (cm: 0 dense, 1 compact, 2 redo)
-extern "C" int smx_query_occupancy(const smx::DevPanel *P, int use64, int use_slots, int cm, size_t lds_bytes, int *blocks_per_cu) {
+extern "C" int smx_query_occupancy(const smx::DevPanel *P, int use64, int use_slots, int cm, int R, size_t lds_bytes, int *blocks_per_cu) {
     const int bsv = demux_bsv(P, use_slots);
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm)), 256, lds_bytes);
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm, R)), 256, lds_bytes);
 }
 
 extern "C" int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,

@@ -173,24 +173,23 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     if (nitems > 0) t.CAPE = 2 * t.CAPH < 256 ? 256 : 2 * t.CAPH;     // (noisy reads of a wide window: two optimal ends per hit)
     if (cap_hits > 0 && cap_hits < t.CAPH) t.CAPH = cap_hits;          // test hook: many small rounds
     if (cap_ents >= S && cap_ents < t.CAPE) t.CAPE = cap_ents;         // (a hit has at most S locations)
+    // Order: regions whose offsets depend on the tile geometry only (R, S) come first -- compile-time constants in the
+    // default-flags kernel --, then the per-alignment regions (R * 2 NP or the compact capacity), the panel tables last.
     int o = 0;
     t.tacc = o;  o += 11 * 8 + 8;
-    t.ppeq = o;  o += t.NPs * 16 * (int)sizeof(PW);
-    t.prpeq = o; o += (need_starts ? t.NPs * 16 * (int)sizeof(PW) : 0);
-    t.bpeq = o;  o += (bs && !slots) ? 0 : t.NBs * 16 * 4;
-    t.BSP = 16 * 16 + 4;                        // words per (primer, 32-barcode word) block of the bit-sliced table (+4: bank skew)
-    t.bsre = o;  o += (bs && !slots) ? NP * t.MBW * t.BSP * 4 : 0;
     t.lut = o;   o += 512;
-    t.pmeta = o; o += npmeta * 4;
+    t.aggr = o;  o += 12 * 4;
     o = (o + 15) & ~15;
     t.codes = o; o += R * 2 * t.CS;
     t.namask = o; o += R * 2 * MW * 4;         // per code row: bit j set = code[j] is not A/C/G/T
     t.lens = o;  o += 2 * R * 4;               // double-buffered: the next tile is encoded while this one is scored
     t.ocnt = o;  o += 2 * R * 4;               // per read: forward votes | reverse votes << 16; double-buffered
     t.rflag = o; o += 2 * R * 4;               // per read: 1 = a window holds something other than upper-case ACGT: scalar primer scan; double-buffered
+    o = (o + 7) & ~7;
+    t.pmask = o; o += R * 8;                   // per read: bit h = alignment h found its primer (scorer: which candidates to look at)
+    o = (o + 15) & ~15;
     t.hits = o;  o += (t.NI + sentinel) * (int)sizeof(HitL);
     t.tiem = o;  o += (t.NI + sentinel) * t.MBW * 4;
-    t.hmap = o;  o += nitems > 0 ? ((R * H + 1) & ~1) * 2 : 0;     // (read, alignment) -> record; t.NI = the shared "no match" record
     t.clist = o; o += nitems > 0 ? ((t.NI + 1) & ~1) * 2 : 0;       // record -> read * H + alignment
     // time-shared regions: {location entries} are dead after the barcode scan -> staged result records;
     // {primer end masks, scans, queue} are dead once the scorer starts -> its emission log
@@ -206,10 +205,17 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.offsB = o; o += (t.NI + 1) * 4;
     t.queue = o; o += ((t.NI + 1) & ~1) * 2;
     if (o < t.emit + R * SMX_MAX_EMIT * 4) o = t.emit + R * SMX_MAX_EMIT * 4;
-    t.aggr = o;  o += 12 * 4;
     o = (o + 7) & ~7;
-    t.pmask = o; o += R * 8;                   // per read: bit h = alignment h found its primer (scorer: which candidates to look at)
+    t.hmap = o;  o += nitems > 0 ? ((R * H + 1) & ~1) * 2 : 0;     // (read, alignment) -> record; t.NI = the shared "no match" record
+    o = (o + 7) & ~7;
     t.hcand = o; o += (H <= 64 ? H : 0) * 8;   // per alignment: the candidates (pair * 2 + orientation) it belongs to
+    o = (o + 15) & ~15;
+    t.ppeq = o;  o += t.NPs * 16 * (int)sizeof(PW);
+    t.prpeq = o; o += (need_starts ? t.NPs * 16 * (int)sizeof(PW) : 0);
+    t.bpeq = o;  o += (bs && !slots) ? 0 : t.NBs * 16 * 4;
+    t.BSP = 16 * 16 + 4;                        // words per (primer, 32-barcode word) block of the bit-sliced table (+4: bank skew)
+    t.bsre = o;  o += (bs && !slots) ? NP * t.MBW * t.BSP * 4 : 0;
+    t.pmeta = o; o += npmeta * 4;
     t.total = (o + 15) & ~15;
     return t;
 }

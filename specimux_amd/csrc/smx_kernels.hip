@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
     const int use_bs = (BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0;
     const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, need_starts, npmeta, sp ? 3 : P->kidx, use_slots, P->bs_ok,
-                                         P->cap_hits, P->cap_ents, aux.nitems);
+                                         sp ? 0 : P->cap_hits, sp ? 0 : P->cap_ents, (sp && CM == 1) ? 256 : aux.nitems);
     // compact mode (aux.nitems > 0, lean launches of many-primer panels behind the prescan): records only for the
     // alignments the prescan's match words flag; a tile with more flagged alignments than records is put on the
     // overflow list and left to the dense redo launch that follows (aux.redo)
@@ -2168,8 +2168,8 @@ int demux_bsv(const smx::DevPanel *P, int use_slots) {
 }
 // the default-flags specialisation applies to the k <= 3 lean kernel (not its tails variant, not the redo launch) with
 // 64-read tiles
-int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm, int R) {
-    return (!use64 && bsv == 1 && cm != 2 && R == 64 && P->S == 80 && P->kidx == 3 && P->maxB <= 32 && !P->need_starts &&
+int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm, int R, int nitems) {
+    return (!use64 && bsv == 1 && cm != 2 && R == 64 && (cm == 0 || nitems == 256) && !P->cap_hits && !P->cap_ents && P->S == 80 && P->kidx == 3 && P->maxB <= 32 && !P->need_starts &&
             P->trim == SMX_TRIM_BARCODES && P->derep == SMX_DEREP_BEST && P->preorient && P->minlen == -1 && P->maxlen == -1 &&
             !getenv("SMX_NO_SPECIALISE")) ? 1 : 0;
 }
@@ -2190,7 +2190,7 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
     // d_tile_counter = {tile queue head, overflow tiles, finished workgroups, extra records}: zero at allocation, re-armed
     // by the last workgroup of every launch (of the last launch of a chain).  Slots mode never uses the bit-sliced scan.
     const int bsv = demux_bsv(P, use_slots), cm = aux.nitems > 0 ? 1 : (aux.redo ? 2 : 0);
-    const void *fn = demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm, R));
+    const void *fn = demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm, R, aux.nitems));
     smx::DevPanel pv = *P;
     unsigned long long *counts = (unsigned long long *)d_counts;
     void *args[] = {&pv, &d_windows, &d_lens, &n_reads, &R, &d_ops, &d_extra, &extra_cap, &d_n_extra, &counts, &d_hits, &d_bdist,
@@ -2218,9 +2218,11 @@ extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
 }
 
 // resident workgroups per CU of the kernel a launch with these parameters would use (cm: 0 dense, 1 compact, 2 redo)
-extern "C" int smx_query_occupancy(const smx::DevPanel *P, int use64, int use_slots, int cm, int R, size_t lds_bytes, int *blocks_per_cu) {
+extern "C" int smx_query_occupancy(const smx::DevPanel *P, int use64, int use_slots, int cm, int R, int nitems, size_t lds_bytes,
+                                   int *blocks_per_cu) {
     const int bsv = demux_bsv(P, use_slots);
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm, R)), 256, lds_bytes);
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm, R, nitems)),
+                                                             256, lds_bytes);
 }
 
 extern "C" int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,

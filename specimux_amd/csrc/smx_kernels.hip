@@ -1100,7 +1100,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     const DevPanel *P = &Pv;
     constexpr bool sp = SP != 0;
     const int R = sp ? 64 : R_arg;   // (the specialised kernel is only launched with 64-read tiles)
-    const int NP = P->NP, NB = P->NB, S = sp ? 80 : P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
+    // SP = 2: SP = 1 for a panel with two primers (one forward, one reverse: a single amplicon) -- the tile's 256
+    // alignments are one per lane, every LDS offset in front of the panel tables is a constant
+    const int NP = SP == 2 ? 2 : P->NP, NB = P->NB, S = sp ? 80 : P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
     const int need_starts = sp ? 0 : P->need_starts;
     const int n_pbc = P->n_pbc, NPAIR = P->NPAIR;
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
@@ -2154,6 +2156,7 @@ const void *demux_fn(int use64, int bsv, int cm, int sp) {
         }
     }
 #define SMX_FN(B, C, S_) (const void *)smx::demux_kernel<unsigned, 256, B, C, S_>
+    if (sp == 2 && bsv == 1 && cm == 0) return SMX_FN(1, 0, 2);
     if (sp && bsv == 1) return cm == 1 ? SMX_FN(1, 1, 1) : SMX_FN(1, 0, 1);
     switch (bsv * 3 + cm) {
         case 0: return SMX_FN(0, 0, 0); case 1: return SMX_FN(0, 1, 0); case 2: return SMX_FN(0, 2, 0);
@@ -2171,7 +2174,7 @@ int demux_bsv(const smx::DevPanel *P, int use_slots) {
 int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm, int R, int nitems) {
     return (!use64 && bsv == 1 && cm != 2 && R == 64 && (cm == 0 || nitems == 256) && !P->cap_hits && !P->cap_ents && P->S == 80 && P->kidx == 3 && P->maxB <= 32 && !P->need_starts &&
             P->trim == SMX_TRIM_BARCODES && P->derep == SMX_DEREP_BEST && P->preorient && P->minlen == -1 && P->maxlen == -1 &&
-            !getenv("SMX_NO_SPECIALISE")) ? 1 : 0;
+            !getenv("SMX_NO_SPECIALISE")) ? ((cm == 0 && P->NP == 2 && !getenv("SMX_NO_SPECIALISE_NP")) ? 2 : 1) : 0;
 }
 }  // namespace
 
@@ -2209,8 +2212,9 @@ extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
     hipError_t e = hipSuccess;
     for (int bsv = 0; bsv < 4; bsv++)
         for (int cm = 0; cm < (use64 ? 1 : 3); cm++)
-            for (int sp = 0; sp < (use64 ? 1 : 2); sp++) {
+            for (int sp = 0; sp < (use64 ? 1 : 3); sp++) {
                 if (sp && (bsv != 1 || cm == 2)) continue;
+                if (sp == 2 && cm != 0) continue;
                 hipError_t r = hipFuncSetAttribute(demux_fn(use64, bsv, cm, sp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
                 if (r != hipSuccess) e = r;
             }

@@ -514,6 +514,7 @@ struct ReadCtx {
     const unsigned short *hmap;   // compact mode: this read's alignment -> record; nullptr: record = alignment
     const unsigned long long *hcand;   // per alignment: bitmask of the candidates it belongs to; nullptr: look at every candidate
     int trim, derep;              // the panel's --trim / --dereplicate (compile-time constants in the default-flags kernel)
+    int npair;                    // primer pairs (a constant 1 in the two-primer kernel)
     unsigned long long pm;        // this read's alignments with a primer match (bit h)
     unsigned long long live;      // candidates (pair * 2 + orientation) worth looking at: one of their alignments matched, and
                                   // the orientation is allowed; all ones when there is no candidate table (hcand == nullptr)
@@ -750,7 +751,7 @@ __device__ inline void emit_partial_or_unknown(Emitter &E, const CandView &v, in
 
 // Iterate the best-scoring candidates in find_candidate_matches order.
 #define FOR_BEST_CANDS(c, ori, best, ...)                                               \
-    for (int _pair = 0; _pair < (c).P->NPAIR; _pair++)                                   \
+    for (int _pair = 0; _pair < (c).npair; _pair++)                                      \
         for (int _o = 0; _o < 2; _o++) {                                                 \
             if ((_o == 0 && (ori) == 2) || (_o == 1 && (ori) == 1)) continue;            \
             if (!(c).cand_live(_pair * 2 + _o)) continue;                                \
@@ -803,7 +804,7 @@ __device__ inline bool score_fast(Emitter &E, int ori, int sub, int G) {
     const DevPanel *P = c.P;
     // ---- select_best_matches (demultiplex.py:216-259): best score, how many carry it, the first of them
     int best = 0, nbest = 0, first = 0x7FFF;
-    const int ncand = P->NPAIR * 2;
+    const int ncand = c.npair * 2;
     const unsigned long long live = c.live;   // (ReadCtx::set_live)
     if (c.hcand) {
         for (unsigned long long m = live; m; m &= m - 1ull) {
@@ -959,7 +960,7 @@ __device__ inline void score_general(Emitter &E, int ori) {
     const ReadCtx &c = *E.c;
     const DevPanel *P = c.P;
     int best = 0;
-    for (int pair = 0; pair < P->NPAIR; pair++)
+    for (int pair = 0; pair < c.npair; pair++)
         for (int o = 0; o < 2; o++) {
             if ((o == 0 && ori == 2) || (o == 1 && ori == 1)) continue;
             if (!c.cand_live(pair * 2 + o)) continue;
@@ -1104,7 +1105,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     // alignments are one per lane, every LDS offset in front of the panel tables is a constant
     const int NP = SP == 2 ? 2 : P->NP, NB = P->NB, S = sp ? 80 : P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
     const int need_starts = sp ? 0 : P->need_starts;
-    const int n_pbc = P->n_pbc, NPAIR = P->NPAIR;
+    const int n_pbc = P->n_pbc, NPAIR = SP == 2 ? 1 : P->NPAIR;
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
     const int use_bs = (BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0;
     const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, need_starts, npmeta, sp ? 3 : P->kidx, use_slots, P->bs_ok,
@@ -1141,7 +1142,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     unsigned short *clist = (unsigned short *)(lds + T.clist);   // compact mode: record -> read * H + alignment
     unsigned long long *pmask = (unsigned long long *)(lds + T.pmask);   // per read: alignments with a primer match
     unsigned long long *hcand = (unsigned long long *)(lds + T.hcand);   // per alignment: its candidates
-    const bool cfilt = H <= 64 && P->NPAIR * 2 <= 64 && P->NPAIR * 2 > 4;   // the scorer looks at matched alignments' candidates only
+    const bool cfilt = H <= 64 && NPAIR * 2 <= 64 && NPAIR * 2 > 4;   // the scorer looks at matched alignments' candidates only
     int tid = threadIdx.x;
     const int wave = tid >> 6;
     // The launch counters re-arm themselves: tile_counter = {tile queue head, overflow tiles, finished workgroups, extra
@@ -1211,7 +1212,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     }
     __syncthreads();
     if (cfilt)
-        for (int ci = tid; ci < P->NPAIR * 2; ci += NT) {   // candidate ci = (pair, orientation): its two alignments (cand_view)
+        for (int ci = tid; ci < NPAIR * 2; ci += NT) {   // candidate ci = (pair, orientation): its two alignments (cand_view)
             const int pair = ci >> 1, o = ci & 1;
             const int h1 = LP.pair_f[pair] * 2 + (o == 0 ? 0 : 1), h2 = LP.pair_r[pair] * 2 + (o == 0 ? 1 : 0);
             atomicOr(&hcand[h1], 1ull << ci);
@@ -1219,7 +1220,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         }
     __syncthreads();
 
-    const int stride = P->wstride;
+    const int stride = sp ? 160 : P->wstride;
     const int kidx = sp ? 3 : P->kidx, pfmin = P->pfmin;
     const int preorient = sp ? 1 : P->preorient, minlen = sp ? -1 : P->minlen, maxlen = sp ? -1 : P->maxlen;
     // Integer division by the (uniform, runtime) item strides: a generic `x / H` is a ~30-instruction sequence on the
@@ -1913,6 +1914,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     ReadCtx c;
                     c.P = P; c.LP = LP; c.MBW = MBW; c.L = L; c.S = S;
                     c.trim = sp ? (int)SMX_TRIM_BARCODES : P->trim; c.derep = sp ? (int)SMX_DEREP_BEST : P->derep;
+                    c.npair = NPAIR;
                     if (cmode) { c.hits = hits; c.tiem = tiem; c.hmap = hmap + r * H; }
                     else { c.hits = hits + r * H; c.tiem = tiem + r * H * MBW; c.hmap = nullptr; }
                     c.hcand = cfilt ? hcand : nullptr;
@@ -2174,7 +2176,7 @@ int demux_bsv(const smx::DevPanel *P, int use_slots) {
 int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm, int R, int nitems) {
     return (!use64 && bsv == 1 && cm != 2 && R == 64 && (cm == 0 || nitems == 256) && !P->cap_hits && !P->cap_ents && P->S == 80 && P->kidx == 3 && P->maxB <= 32 && !P->need_starts &&
             P->trim == SMX_TRIM_BARCODES && P->derep == SMX_DEREP_BEST && P->preorient && P->minlen == -1 && P->maxlen == -1 &&
-            !getenv("SMX_NO_SPECIALISE")) ? ((cm == 0 && P->NP == 2 && !getenv("SMX_NO_SPECIALISE_NP")) ? 2 : 1) : 0;
+            !getenv("SMX_NO_SPECIALISE")) ? ((cm == 0 && P->NP == 2 && P->NPAIR == 1 && !getenv("SMX_NO_SPECIALISE_NP")) ? 2 : 1) : 0;
 }
 }  // namespace
 

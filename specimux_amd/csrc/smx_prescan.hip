@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256) void prescan_transpose_kernel(int S, const uin
     }
 }
 
-// ---- DP kernel: one wave per (tile, primer); NX = extra (degenerate-letter) symbol rows; MR = DP rows compiled in: 24
-// when every primer has <= 24 nt, else 31 (one variant per kernel: two DP bodies in one kernel made the register
+// ---- DP kernel: one wave per (tile, primer); NX = extra (degenerate-letter) symbol rows; MR = DP rows compiled in: 22 or
+// 24 when every primer has at most that many nt, else 31 (one variant per kernel: two DP bodies in one kernel made the register
 // allocator spill hundreds of registers)
 #ifndef SMX_PRE_WAVES
 #define SMX_PRE_WAVES 2   // waves per SIMD the DP kernel's register allocation aims at
@@ -131,10 +131,11 @@ extern "C" size_t smx_prescan_lds_bytes(int S) {   // the transpose kernel's sta
     return ((size_t)smx::PRE_G * (2 * (S >> 4)) * smx::PRE_BLK + 64) * 4;
 }
 
-#define SMX_PRE_VARIANTS(X) X(24, 0) X(24, 4) X(31, 0) X(31, 4)
+#define SMX_PRE_VARIANTS(X) X(22, 0) X(22, 4) X(24, 0) X(24, 4) X(31, 0) X(31, 4)
+static int prescan_rows(int mr) { return mr <= 22 ? 22 : (mr <= 24 ? 24 : 31); }   // DP rows compiled in: inert rows cost as much as live ones
 
 static const void *prescan_fn(int mr, int nx) {
-    const int mrv = mr <= 24 ? 24 : 31, nxv = nx > 0 ? 4 : 0;
+    const int mrv = prescan_rows(mr), nxv = nx > 0 ? 4 : 0;
 #define X(MRV, NXV) if (mrv == MRV && nxv == NXV) return (const void *)smx::prescan_dp_kernel<MRV, NXV, 1>;
     SMX_PRE_VARIANTS(X)
 #undef X
@@ -154,7 +155,7 @@ extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int gri
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);   // diagnostic: boundary between the two kernels
-    const int mrv = mr <= 24 ? 24 : 31, nxv = nx > 0 ? 4 : 0;
+    const int mrv = prescan_rows(mr), nxv = nx > 0 ? 4 : 0;
 #define X(MRV, NXV)                                                                                            \
     if (mrv == MRV && nxv == NXV) {                                                                            \
         if (d_match)                                                                                           \

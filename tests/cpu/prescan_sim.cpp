@@ -129,7 +129,8 @@ int main(int argc, char **argv) {
         for (int lane = 0; lane < 64; lane++) {   // phase 3: lane = (group, end)
             const int g = lane >> 1, X = lane & 1;
             unsigned mword = 0;
-            if (D.m[p] <= 24) prescan_dp<24, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32, &mword);
+            if (D.m[p] <= 22 && (p & 1)) prescan_dp<22, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32, &mword);   // (both row counts that fit)
+            else if (D.m[p] <= 24) prescan_dp<24, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32, &mword);
             else prescan_dp<31, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32, &mword);
             for (int r = 0; r < 32; r++) {
                 const int read = g * 32 + r;

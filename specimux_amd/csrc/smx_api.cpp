@@ -522,7 +522,7 @@ static int ensure_device(smx_panel *P) {
         if (P->pre_lds > 64 * 1024 && smx_prescan_set_lds_limit(P->pre_lds) != 0)
             return fail(SMX_ERR_DEVICE, "cannot raise the prescan kernel's dynamic LDS limit to %zu bytes", P->pre_lds);
         int occ_t = 0, occ_d = 0;
-        if (smx_prescan_occupancy(P->pre_mr, P->pre_nx, P->pre_lds, &occ_t, &occ_d) != 0 || occ_t < 1 || occ_d < 1) { occ_t = 1; occ_d = 8; }
+        if (smx_prescan_occupancy(P->hp.S, P->pre_mr, P->pre_nx, P->pre_lds, &occ_t, &occ_d) != 0 || occ_t < 1 || occ_d < 1) { occ_t = 1; occ_d = 8; }
         P->pre_blocks_t = occ_t;
         P->pre_blocks_d = occ_d;
         if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] prescan: transpose %d workgroups/CU (lds %zu), DP %d waves/CU\n", occ_t, P->pre_lds, occ_d);

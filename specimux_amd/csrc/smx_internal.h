@@ -72,7 +72,8 @@ int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int grid_t, size_t
                        const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride, unsigned *d_planes,
                        unsigned *d_out, unsigned *d_match, void *ev_mid);
 int smx_prescan_set_lds_limit(size_t bytes);
-int smx_prescan_occupancy(int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d);
+int smx_prescan_occupancy(int S, int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d);
+int smx_prescan_transpose_threads(int S);
 size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta, int kidx,
                            int slots, int bs, int nitems);
 int smx_set_demux_lds_limit(int use64, size_t bytes);

@@ -19,11 +19,13 @@
 namespace smx {
 
 // ---- transpose kernel: windows -> 2-bit planes, bit-sliced over the 32 reads of a group (layout: prescan_plane_word)
-__global__ __launch_bounds__(256) void prescan_transpose_kernel(int S, const uint8_t *__restrict__ windows,
-                                                                const int32_t *__restrict__ lens, uint32_t n_reads, int stride,
-                                                                unsigned *__restrict__ gplanes, uint32_t ntiles) {
+// NT = 320 threads when the tile's 32 x (2 S / 16) blocks are a multiple of 320 (search_len 80: 320 blocks = exactly one
+// transpose pass of five waves instead of one full pass of four plus one with a single wave busy), else 256.
+template <int NT>
+__global__ __launch_bounds__(NT) void prescan_transpose_kernel(int S, const uint8_t *__restrict__ windows,
+                                                               const int32_t *__restrict__ lens, uint32_t n_reads, int stride,
+                                                               unsigned *__restrict__ gplanes, uint32_t ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned plds[];
-    constexpr int NT = 256;
     const int tid = threadIdx.x;
     const int CH = S >> 4, ppr = 2 * CH;
     unsigned *planes = plds;
@@ -65,16 +67,17 @@ __global__ __launch_bounds__(256) void prescan_transpose_kernel(int S, const uin
         // ---- phase 1b: reads shorter than the window (rare): their head pieces again, right-aligned
         // (prescan_short_head_piece); kept out of the streaming loop, where the length load would sit in front of a branch
         {
-            int Ls[PRE_TILE / NT];
+            constexpr int NL = (PRE_TILE + NT - 1) / NT;
+            int Ls[NL];
 #pragma unroll
-            for (int u = 0; u < PRE_TILE / NT; u++) {   // all length loads first
+            for (int u = 0; u < NL; u++) {   // all length loads first
                 const uint32_t rd = r0 + (uint32_t)(tid + u * NT);
                 Ls[u] = lens[rd < n_reads ? rd : n_reads - 1];
             }
 #pragma unroll
-            for (int u = 0; u < PRE_TILE / NT; u++) {
+            for (int u = 0; u < NL; u++) {
                 const int read = tid + u * NT;
-                if (r0 + (uint32_t)read < n_reads && Ls[u] < S) {
+                if (read < PRE_TILE && r0 + (uint32_t)read < n_reads && Ls[u] < S) {
                     const uint8_t *row = windows + (size_t)(r0 + (uint32_t)read) * stride;
                     for (int c = 0; c < CH; c++) {
                         unsigned w4[4];
@@ -127,6 +130,10 @@ __global__ __launch_bounds__(64, SMX_PRE_WAVES) void prescan_dp_kernel(PreDesc D
 
 }  // namespace smx
 
+// the streaming phase wants 1024 x pieces-per-read to be a multiple of 8 x threads, the transpose phase 32 x pieces-per-read
+// blocks a multiple of the threads: 320 threads when pieces-per-read (2 S / 16) is a multiple of 10
+extern "C" int smx_prescan_transpose_threads(int S) { return ((2 * (S >> 4)) % 10) == 0 ? 320 : 256; }
+
 extern "C" size_t smx_prescan_lds_bytes(int S) {   // the transpose kernel's staging blocks
     return ((size_t)smx::PRE_G * (2 * (S >> 4)) * smx::PRE_BLK + 64) * 4;
 }
@@ -150,8 +157,12 @@ extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int gri
     static_assert(smx::PRE_MAXROWS == 31 && smx::PRE_MAXSYM == 8, "variant table");
     const uint32_t ntiles = (n_reads + smx::PRE_TILE - 1) / smx::PRE_TILE;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(smx::prescan_transpose_kernel, dim3(grid_t), dim3(256), lds_t, s, D->S, d_windows, d_lens, n_reads,
-                       stride, d_planes, ntiles);
+    if (smx_prescan_transpose_threads(D->S) == 320)
+        hipLaunchKernelGGL(smx::prescan_transpose_kernel<320>, dim3(grid_t), dim3(320), lds_t, s, D->S, d_windows, d_lens, n_reads,
+                           stride, d_planes, ntiles);
+    else
+        hipLaunchKernelGGL(smx::prescan_transpose_kernel<256>, dim3(grid_t), dim3(256), lds_t, s, D->S, d_windows, d_lens, n_reads,
+                           stride, d_planes, ntiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);   // diagnostic: boundary between the two kernels
@@ -169,12 +180,15 @@ extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int gri
 }
 
 extern "C" int smx_prescan_set_lds_limit(size_t bytes) {
-    return (int)hipFuncSetAttribute((const void *)smx::prescan_transpose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)bytes);
+    hipError_t e = hipFuncSetAttribute((const void *)smx::prescan_transpose_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipError_t e2 = hipFuncSetAttribute((const void *)smx::prescan_transpose_kernel<320>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return (int)(e != hipSuccess ? e : e2);
 }
 
-extern "C" int smx_prescan_occupancy(int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d) {
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_t, (const void *)smx::prescan_transpose_kernel, 256, lds_t);
+extern "C" int smx_prescan_occupancy(int S, int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d) {
+    const int nt = smx_prescan_transpose_threads(S);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        blocks_t, nt == 320 ? (const void *)smx::prescan_transpose_kernel<320> : (const void *)smx::prescan_transpose_kernel<256>, nt, lds_t);
     if (e != hipSuccess) return (int)e;
     return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_d, prescan_fn(mr, nx), 64, 0);
 }

@@ -346,7 +346,9 @@ def main():
     _lib.check(lib.smx_debug_kernel_times(cp.handle, 0, None))
     k_t, k_d, k_b = (float(x) for x in kms.mean(axis=0))
     bsv = 1 if parameters.max_dist_index < 4 and (a.trim or "") != "tails" else (3 if parameters.max_dist_index < 4 else 2)
-    demux_name = f"smx::demux_kernel<unsigned int, 256, {bsv}>"
+    # (template arguments after the scan variant -- compact / redo mode, default-flags specialisation -- are chosen by the
+    # launch glue from the panel; panels with compact tiles launch the kernel twice per step, both are in this time)
+    demux_name = f"smx::demux_kernel<unsigned int, 256, {bsv}, ...>"
     step_kernels = [{"kernel": "smx::prescan_transpose_kernel", "ms": k_t}, {"kernel": "smx::prescan_dp_kernel", "ms": k_d},
                     {"kernel": demux_name, "ms": k_b}]
     kernels_ms = k_t + k_d + k_b

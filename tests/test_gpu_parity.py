@@ -695,3 +695,19 @@ def test_compact_tiles_forced_on_two_primer_panel(lib, c2, monkeypatch):
         both = Both(pf, sf, **fl)
         both.assert_hits_equal(reads[:150], f"compact c2 {fl}", lean=True)
         both.assert_ops_equal(reads, f"compact c2 {fl}")
+
+
+@pytest.mark.parametrize("env", [dict(SMX_NO_SPECIALISE="1"), dict(SMX_NO_SPECIALISE_NP="1")], ids=lambda e: ",".join(e))
+def test_generic_kernel_on_default_flags(lib, c2, c3, monkeypatch, env):
+    """The reference's default flags normally run the specialised instantiations of the lean kernel (search_len 80, index
+    distance 3, trim barcodes, ... as compile-time constants; a further one for two-primer panels).  With the
+    specialisation switched off the generic instantiation serves the same panels: same records, same hit tables."""
+    from specimux_amd import synth
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name, (pan, (pf, sf)), kw in (("c2", c2, {}), ("c3", c3, dict(insert_mean=900, insert_sd=250))):
+        rs = synth.make_reads(pan, 1200, 4242, windows_only=False, **kw)
+        reads = reads_from_set(rs, range(1200), 80) + ([r for r in _edge_reads(pan) if r[0] != "u_base"] if name == "c2" else [])
+        both = Both(pf, sf)
+        both.assert_hits_equal(reads[:150], f"generic {env} {name}", lean=True)
+        both.assert_ops_equal(reads, f"generic {env} {name}")

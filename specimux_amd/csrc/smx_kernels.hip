@@ -28,6 +28,9 @@
 // forms are about half rate; generic integer division is avoided in per-item code).  See DESIGN.md for the data
 // layout, the exactness arguments and the rooflines.
 #include <hip/hip_runtime.h>
+#ifndef SMX_PART
+#error "compile with -DSMX_PART=1, 2 or 3 (see the Makefile)"
+#endif
 #include <stdint.h>
 #include "smx.h"
 #include "smx_internal.h"
@@ -2062,6 +2065,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     if (tid == 0) workgroup_done();
 }
 
+#if SMX_PART == 1
 // ------------------------------------------------------------------------------------------------
 // Single alignment (smx_align): one lane, same column step, arbitrary target length.
 __global__ void align_kernel(const unsigned long long *peq, const unsigned long long *rpeq, int m,
@@ -2142,13 +2146,20 @@ __global__ __launch_bounds__(64) void align_batch_kernel(const unsigned long lon
     out_nloc[i] = cnt;
 }
 
+#endif   // SMX_PART == 1 (alignment kernels)
+
 }  // namespace smx
 
 // ------------------------------------------------------------------------------------------------
 // launch glue used by smx_api.cpp
-namespace {
-// one instantiation per (primer word width, barcode scan variant, compact / redo mode, default-flags specialisation)
-const void *demux_fn(int use64, int bsv, int cm, int sp) {
+// The kernel's instantiations -- one per (primer word width, barcode scan variant, compact / redo mode, default-flags
+// specialisation): 19 of them, half a minute of compile time each -- are spread over three translation units: this file is
+// compiled three times (-DSMX_PART=1 / 2 / 3, in parallel), each part instantiates the kernels its table names, part 1 also
+// holds the alignment kernels and the glue.
+#define SMX_FN(B, C, S_) (const void *)smx::demux_kernel<unsigned, 256, B, C, S_>
+#if SMX_PART == 1
+extern "C" const void *smx_demux_fn_p1(int use64, int bsv, int cm, int sp) {   // 64-bit primer words; per-barcode scan (BSV 0)
+    (void)sp;
     if (use64) {
         switch (bsv) {
             case 0: return (const void *)smx::demux_kernel<unsigned long long, 256, 0>;
@@ -2157,16 +2168,32 @@ const void *demux_fn(int use64, int bsv, int cm, int sp) {
             default: return (const void *)smx::demux_kernel<unsigned long long, 256, 3>;
         }
     }
-#define SMX_FN(B, C, S_) (const void *)smx::demux_kernel<unsigned, 256, B, C, S_>
-    if (sp == 2 && bsv == 1 && cm == 0) return SMX_FN(1, 0, 2);
-    if (sp && bsv == 1) return cm == 1 ? SMX_FN(1, 1, 1) : SMX_FN(1, 0, 1);
-    switch (bsv * 3 + cm) {
-        case 0: return SMX_FN(0, 0, 0); case 1: return SMX_FN(0, 1, 0); case 2: return SMX_FN(0, 2, 0);
-        case 3: return SMX_FN(1, 0, 0); case 4: return SMX_FN(1, 1, 0); case 5: return SMX_FN(1, 2, 0);
-        case 6: return SMX_FN(2, 0, 0); case 7: return SMX_FN(2, 1, 0); case 8: return SMX_FN(2, 2, 0);
-        case 9: return SMX_FN(3, 0, 0); case 10: return SMX_FN(3, 1, 0); default: return SMX_FN(3, 2, 0);
-    }
+    return cm == 0 ? SMX_FN(0, 0, 0) : (cm == 1 ? SMX_FN(0, 1, 0) : SMX_FN(0, 2, 0));
+}
+#elif SMX_PART == 2
+extern "C" const void *smx_demux_fn_p2(int use64, int bsv, int cm, int sp) {   // bit-sliced scans k <= 3 and k 4..7, generic
+    (void)use64; (void)sp;
+    if (bsv == 1) return cm == 0 ? SMX_FN(1, 0, 0) : (cm == 1 ? SMX_FN(1, 1, 0) : SMX_FN(1, 2, 0));
+    return cm == 0 ? SMX_FN(2, 0, 0) : (cm == 1 ? SMX_FN(2, 1, 0) : SMX_FN(2, 2, 0));
+}
+#else
+extern "C" const void *smx_demux_fn_p3(int use64, int bsv, int cm, int sp) {   // the tails variant; the default-flags kernels
+    (void)use64;
+    if (bsv == 3) return cm == 0 ? SMX_FN(3, 0, 0) : (cm == 1 ? SMX_FN(3, 1, 0) : SMX_FN(3, 2, 0));
+    if (sp == 2) return SMX_FN(1, 0, 2);
+    return cm == 1 ? SMX_FN(1, 1, 1) : SMX_FN(1, 0, 1);
+}
+#endif
 #undef SMX_FN
+
+#if SMX_PART == 1
+extern "C" const void *smx_demux_fn_p2(int use64, int bsv, int cm, int sp);
+extern "C" const void *smx_demux_fn_p3(int use64, int bsv, int cm, int sp);
+namespace {
+const void *demux_fn(int use64, int bsv, int cm, int sp) {
+    if (use64 || bsv == 0) return smx_demux_fn_p1(use64, bsv, cm, sp);
+    if (bsv == 3 || (sp && bsv == 1 && cm != 2)) return smx_demux_fn_p3(use64, bsv, cm, cm == 0 ? sp : 1);
+    return smx_demux_fn_p2(use64, bsv, cm, sp);
 }
 int demux_bsv(const smx::DevPanel *P, int use_slots) {
     return (use_slots || !P->bs_ok) ? 0 : (P->kidx < 4 ? (P->trim == SMX_TRIM_TAILS ? 3 : 1) : 2);
@@ -2248,3 +2275,4 @@ extern "C" int smx_launch_align_batch(void *stream, const unsigned long long *d_
                        d_tcodes, d_toff, d_k, d_modes, n, d_ws, d_dist, d_nloc, d_starts, d_ends, cap);
     return (int)hipGetLastError();
 }
+#endif   // SMX_PART == 1 (glue)

@@ -190,7 +190,8 @@ int smx_batch_run_device(const smx_panel *panel, void *stream, const uint8_t *d_
  * Diagnostic: per-kernel device times of smx_batch_run_device on this panel.  enable != 0 makes every following launch
  * record HIP events around its kernels (transpose, primer DP, demux) on the launch stream; with ms != NULL the call waits
  * for the most recent instrumented launch and writes its three durations in milliseconds (0 for a kernel that did not
- * run).  Off by default: the events cost a few microseconds per launch.
+ * run; panels with many primers launch the demux kernel twice per batch -- compact tiles, then the reads of the tiles
+ * that did not fit: the third duration covers both).  Off by default: the events cost a few microseconds per launch.
  */
 int smx_debug_kernel_times(smx_panel *panel, int enable, float ms[3]);
 

@@ -1253,7 +1253,9 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     // diagnostic phase timing (SMX_PHASE_TIMING=1): thread 0 accumulates s_memtime deltas per phase, in LDS so that
     // the accumulators cost no registers in the production path
     unsigned long long *tacc = (unsigned long long *)(lds + T.tacc);   // [0..9] sums, [10] previous stamp
-    const bool timing = P->dbg_phase != nullptr && tid == 0;
+    // (the default-flags kernels carry no phase timing: SMX_PHASE_TIMING runs use the generic instantiation)
+    unsigned long long *const dbg_phase = sp ? nullptr : P->dbg_phase;
+    const bool timing = dbg_phase != nullptr && tid == 0;
     if (timing) for (int i = 0; i < 11; i++) tacc[i] = 0;
 // STAMP marks a phase boundary: optional timing, and tid is laundered so that per-thread values are recomputed by
 // the phase that needs them instead of being computed early and carried (spilled) across the register-hungry scans
@@ -1946,7 +1948,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         } else if (nxt < n_tiles) {
             // ---- phase 1 (of the NEXT tile): windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
             const int wid = live ? tid - 64 * SW : tid, nw = live ? NT - 64 * SW : NT;
-            const bool timing_enc = P->dbg_phase != nullptr && tid == 64 * SW;   // diagnostic: this wave's own encode time
+            const bool timing_enc = dbg_phase != nullptr && tid == 64 * SW;   // diagnostic: this wave's own encode time
             unsigned long long t_enc0 = 0;
             if (timing_enc) t_enc0 = clock64();
             uint32_t r0n;
@@ -2054,10 +2056,10 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         // (no barrier needed here: the next writers of hits / masks / opsL come after the barriers of phase 2)
     }
     if (timing)
-        for (int i = 0; i < 10; i++) P->dbg_phase[(size_t)blockIdx.x * 16 + i] += tacc[i];
-    if (timing) P->dbg_phase[(size_t)blockIdx.x * 16 + 14] += tacc[0] != 0 || tacc[1] != 0 ? 1 : 0;   // did this workgroup get any tile?
-    if (P->dbg_phase != nullptr && (tid & 63) == 0)   // placement of this wave: HW_ID (simd, wave slot, cu, se)
-        P->dbg_phase[(size_t)blockIdx.x * 16 + 10 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+        for (int i = 0; i < 10; i++) dbg_phase[(size_t)blockIdx.x * 16 + i] += tacc[i];
+    if (timing) dbg_phase[(size_t)blockIdx.x * 16 + 14] += tacc[0] != 0 || tacc[1] != 0 ? 1 : 0;   // did this workgroup get any tile?
+    if (dbg_phase != nullptr && (tid & 63) == 0)   // placement of this wave: HW_ID (simd, wave slot, cu, se)
+        dbg_phase[(size_t)blockIdx.x * 16 + 10 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
 #undef STAMP
     // block aggregates -> global counters
     if (tid < 8 && aggr[tid]) atomicAdd(&counts[tid], (unsigned long long)aggr[tid]);
@@ -2203,6 +2205,7 @@ int demux_bsv(const smx::DevPanel *P, int use_slots) {
 int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm, int R, int nitems) {
     return (!use64 && bsv == 1 && cm != 2 && R == 64 && (cm == 0 || nitems == 256) && !P->cap_hits && !P->cap_ents && P->S == 80 && P->kidx == 3 && P->maxB <= 32 && !P->need_starts &&
             P->trim == SMX_TRIM_BARCODES && P->derep == SMX_DEREP_BEST && P->preorient && P->minlen == -1 && P->maxlen == -1 &&
+            !P->dbg_phase &&
             !getenv("SMX_NO_SPECIALISE")) ? ((cm == 0 && P->NP == 2 && P->NPAIR == 1 && !getenv("SMX_NO_SPECIALISE_NP")) ? 2 : 1) : 0;
 }
 }  // namespace

@@ -1103,10 +1103,11 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
     constexpr bool sp = SP != 0;
-    const int R = sp ? 64 : R_arg;   // (the specialised kernel is only launched with 64-read tiles)
+    // SP = 3: SP = 1 with search_len 160 and 32-read tiles (the wide-window stress shape of a many-primer panel)
+    const int R = SP == 3 ? 32 : (sp ? 64 : R_arg);   // (the specialised kernels are only launched with these tile sizes)
     // SP = 2: SP = 1 for a panel with two primers (one forward, one reverse: a single amplicon) -- the tile's 256
     // alignments are one per lane, every LDS offset in front of the panel tables is a constant
-    const int NP = SP == 2 ? 2 : P->NP, NB = P->NB, S = sp ? 80 : P->S, H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
+    const int NP = SP == 2 ? 2 : P->NP, NB = P->NB, S = SP == 3 ? 160 : (sp ? 80 : P->S), H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
     const int need_starts = sp ? 0 : P->need_starts;
     const int n_pbc = P->n_pbc, NPAIR = SP == 2 ? 1 : P->NPAIR;
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
@@ -1223,7 +1224,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         }
     __syncthreads();
 
-    const int stride = sp ? 160 : P->wstride;
+    const int stride = SP == 3 ? 320 : (sp ? 160 : P->wstride);
     const int kidx = sp ? 3 : P->kidx, pfmin = P->pfmin;
     const int preorient = sp ? 1 : P->preorient, minlen = sp ? -1 : P->minlen, maxlen = sp ? -1 : P->maxlen;
     // Integer division by the (uniform, runtime) item strides: a generic `x / H` is a ~30-instruction sequence on the
@@ -1317,7 +1318,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             if (use_pre) {
                 const uint32_t gr = r0 + (uint32_t)r;   // flag words: [tile of 1024 reads][alignment h][chunk][read in tile]
                 const unsigned *pw = pre + ((size_t)(gr >> 10) * H + h) * (S >> 4) * PRE_TILE + (gr & (PRE_TILE - 1));
-                const int bfull = S == 80 ? prescan_decode<5>(pw, PRE_TILE, 5, MW, m, k, g.Sp, mrow, &jstar, &cnt)   // the default -l
+                const int bfull = S == 160 ? prescan_decode<10>(pw, PRE_TILE, 10, MW, m, k, g.Sp, mrow, &jstar, &cnt)
+                                : S == 80 ? prescan_decode<5>(pw, PRE_TILE, 5, MW, m, k, g.Sp, mrow, &jstar, &cnt)   // the default -l
                                           : prescan_decode<0>(pw, PRE_TILE, S >> 4, MW, m, k, g.Sp, mrow, &jstar, &cnt);
                 pre_omatch = bfull <= k;
                 if (g.j_lo == 0) { pre_done = true; best = pre_omatch ? bfull : m + 1; }
@@ -2183,6 +2185,7 @@ extern "C" const void *smx_demux_fn_p3(int use64, int bsv, int cm, int sp) {   /
     (void)use64;
     if (bsv == 3) return cm == 0 ? SMX_FN(3, 0, 0) : (cm == 1 ? SMX_FN(3, 1, 0) : SMX_FN(3, 2, 0));
     if (sp == 2) return SMX_FN(1, 0, 2);
+    if (sp == 3) return SMX_FN(1, 1, 3);
     return cm == 1 ? SMX_FN(1, 1, 1) : SMX_FN(1, 0, 1);
 }
 #endif
@@ -2194,7 +2197,7 @@ extern "C" const void *smx_demux_fn_p3(int use64, int bsv, int cm, int sp);
 namespace {
 const void *demux_fn(int use64, int bsv, int cm, int sp) {
     if (use64 || bsv == 0) return smx_demux_fn_p1(use64, bsv, cm, sp);
-    if (bsv == 3 || (sp && bsv == 1 && cm != 2)) return smx_demux_fn_p3(use64, bsv, cm, cm == 0 ? sp : 1);
+    if (bsv == 3 || (sp && bsv == 1 && cm != 2)) return smx_demux_fn_p3(use64, bsv, cm, sp);
     return smx_demux_fn_p2(use64, bsv, cm, sp);
 }
 int demux_bsv(const smx::DevPanel *P, int use_slots) {
@@ -2203,10 +2206,13 @@ int demux_bsv(const smx::DevPanel *P, int use_slots) {
 // the default-flags specialisation applies to the k <= 3 lean kernel (not its tails variant, not the redo launch) with
 // 64-read tiles
 int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm, int R, int nitems) {
-    return (!use64 && bsv == 1 && cm != 2 && R == 64 && (cm == 0 || nitems == 256) && !P->cap_hits && !P->cap_ents && P->S == 80 && P->kidx == 3 && P->maxB <= 32 && !P->need_starts &&
-            P->trim == SMX_TRIM_BARCODES && P->derep == SMX_DEREP_BEST && P->preorient && P->minlen == -1 && P->maxlen == -1 &&
-            !P->dbg_phase &&
-            !getenv("SMX_NO_SPECIALISE")) ? ((cm == 0 && P->NP == 2 && P->NPAIR == 1 && !getenv("SMX_NO_SPECIALISE_NP")) ? 2 : 1) : 0;
+    const bool flags = !use64 && bsv == 1 && cm != 2 && (cm == 0 || nitems == 256) && !P->cap_hits && !P->cap_ents &&
+                       P->kidx == 3 && P->maxB <= 32 && !P->need_starts && P->trim == SMX_TRIM_BARCODES && P->derep == SMX_DEREP_BEST &&
+                       P->preorient && P->minlen == -1 && P->maxlen == -1 && !P->dbg_phase && !getenv("SMX_NO_SPECIALISE");
+    if (!flags) return 0;
+    if (P->S == 160 && R == 32 && cm == 1) return 3;                       // wide windows, compact 32-read tiles
+    if (P->S != 80 || R != 64) return 0;
+    return (cm == 0 && P->NP == 2 && P->NPAIR == 1 && !getenv("SMX_NO_SPECIALISE_NP")) ? 2 : 1;
 }
 }  // namespace
 
@@ -2244,9 +2250,10 @@ extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
     hipError_t e = hipSuccess;
     for (int bsv = 0; bsv < 4; bsv++)
         for (int cm = 0; cm < (use64 ? 1 : 3); cm++)
-            for (int sp = 0; sp < (use64 ? 1 : 3); sp++) {
+            for (int sp = 0; sp < (use64 ? 1 : 4); sp++) {
                 if (sp && (bsv != 1 || cm == 2)) continue;
                 if (sp == 2 && cm != 0) continue;
+                if (sp == 3 && cm != 1) continue;
                 hipError_t r = hipFuncSetAttribute(demux_fn(use64, bsv, cm, sp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
                 if (r != hipSuccess) e = r;
             }

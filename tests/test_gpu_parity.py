@@ -705,9 +705,10 @@ def test_generic_kernel_on_default_flags(lib, c2, c3, monkeypatch, env):
     from specimux_amd import synth
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    for name, (pan, (pf, sf)), kw in (("c2", c2, {}), ("c3", c3, dict(insert_mean=900, insert_sd=250))):
-        rs = synth.make_reads(pan, 1200, 4242, windows_only=False, **kw)
-        reads = reads_from_set(rs, range(1200), 80) + ([r for r in _edge_reads(pan) if r[0] != "u_base"] if name == "c2" else [])
-        both = Both(pf, sf)
+    for name, (pan, (pf, sf)), S, kw in (("c2", c2, 80, {}), ("c3", c3, 80, dict(insert_mean=900, insert_sd=250)),
+                                       ("c5", c3, 160, dict(error_rate=0.15))):   # (the -l 160 shape has its own instantiation)
+        rs = synth.make_reads(pan, 1200 if S == 80 else 500, 4242, search_len=S, windows_only=False, **kw)
+        reads = reads_from_set(rs, range(len(rs.lens)), S) + ([r for r in _edge_reads(pan) if r[0] != "u_base"] if name == "c2" else [])
+        both = Both(pf, sf, **({} if S == 80 else dict(search_len=S)))
         both.assert_hits_equal(reads[:150], f"generic {env} {name}", lean=True)
         both.assert_ops_equal(reads, f"generic {env} {name}")

@@ -712,3 +712,32 @@ def test_generic_kernel_on_default_flags(lib, c2, c3, monkeypatch, env):
         both = Both(pf, sf, **({} if S == 80 else dict(search_len=S)))
         both.assert_hits_equal(reads[:150], f"generic {env} {name}", lean=True)
         both.assert_ops_equal(reads, f"generic {env} {name}")
+
+
+@pytest.mark.parametrize("shape", ["mixed_lengths", "24nt_barcodes", "96x4_multiword", "16nt_barcodes_k5"])
+def test_compact_tiles_other_scan_variants(lib, tmp_path_factory, monkeypatch, shape):
+    """Compact tiles under the barcode-scan variants the default panels do not reach: the per-barcode lean scan (mixed
+    lengths, 24-nt barcodes), three tie-mask words per hit, the k 4..7 bit-sliced scan -- forced on, with a record
+    capacity that every tile fits and one that sends most tiles through the overflow list and the redo launch."""
+    from specimux_amd import synth
+    flags = {}
+    if shape == "mixed_lengths":
+        pan, (pf, sf) = _custom_panel(tmp_path_factory, "cm_" + shape, 8, 6, 13, 6, mixed=True)
+        flags = dict(disable_prefilter=True)
+    elif shape == "24nt_barcodes":
+        pan, (pf, sf) = _custom_panel(tmp_path_factory, "cm_" + shape, 12, 8, 24, 10)
+        flags = dict(disable_prefilter=True)
+    elif shape == "96x4_multiword":
+        pan, (pf, sf) = _custom_panel(tmp_path_factory, "cm_" + shape, 96, 4, 13, 5)
+    else:
+        pan, (pf, sf) = _custom_panel(tmp_path_factory, "cm_" + shape, 8, 6, 16, 7)
+        flags = dict(index_edit_distance=5)
+    rs = synth.make_reads(pan, 600, 123, windows_only=False, n_frac=0.03)
+    reads = reads_from_set(rs, range(600), 80)
+    for items in ("176", "120"):   # every tile fits / most tiles go through the overflow list (measured with SMX_DEBUG_OVERFLOW)
+        monkeypatch.setenv("SMX_COMPACT_ITEMS", items)
+        for fl in (flags, dict(flags, trim="primers")):
+            both = Both(pf, sf, **fl)
+            both.assert_hits_equal(reads[:100], f"compact {shape} {fl} {items}", lean=True)
+            got = both.assert_ops_equal(reads, f"compact {shape} {fl} {items}")
+            assert sum(1 for k in got if k[6] == "DEREP") > 100

@@ -1097,8 +1097,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R_arg,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
-                                                    unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist,
-                                                    unsigned *tile_counter, int use_slots,
+                                                    unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist_arg,
+                                                    unsigned *tile_counter, int use_slots_arg,
                                                     const unsigned *__restrict__ pre, uint32_t npad, DemuxAux aux) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DevPanel *P = &Pv;
@@ -1111,7 +1111,10 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     const int need_starts = sp ? 0 : P->need_starts;
     const int n_pbc = P->n_pbc, NPAIR = SP == 2 ? 1 : P->NPAIR;
     const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
-    const int use_bs = (BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0;
+    // (the default-flags kernels are lean bit-sliced launches by construction: no slots-mode state in them)
+    const int use_slots = SP != 0 ? 0 : use_slots_arg;
+    int8_t *const dbg_bdist = SP != 0 ? nullptr : dbg_bdist_arg;
+    const int use_bs = SP != 0 ? 1 : ((BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0);
     const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, need_starts, npmeta, sp ? 3 : P->kidx, use_slots, P->bs_ok,
                                          sp ? 0 : P->cap_hits, sp ? 0 : P->cap_ents, (sp && CM == 1) ? 256 : aux.nitems);
     // compact mode (aux.nitems > 0, lean launches of many-primer panels behind the prescan): records only for the

@@ -43,7 +43,7 @@ typedef enum {
     SMX_ERR_ARG = -1,      /* bad argument / inconsistent descriptor */
     SMX_ERR_UNSUPPORTED = -2, /* panel outside the kernel's limits (pattern > 64 nt, ...) */
     SMX_ERR_DEVICE = -3,   /* HIP error or no device */
-    SMX_ERR_OVERFLOW = -4  /* a read produced more write operations than the kernel can emit */
+    SMX_ERR_OVERFLOW = -4  /* the extra-record buffer was too small (retry with the reported size), or one read produced more than 65535 write operations (n_ops is 16 bits) */
 } smx_status;
 
 /* trim modes (constants.py:40-45) and dereplication strategies (:48-51) */

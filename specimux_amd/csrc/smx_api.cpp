@@ -118,6 +118,7 @@ struct smx_panel {
     size_t o_ppeq, o_prpeq, o_bpeq, o_lut, o_pm, o_pk, o_pdir, o_pfidx, o_pbc_off, o_pbc, o_bm, o_pair_f, o_pair_r,
         o_pair_pool, o_bsre, o_pairrec = 0, o_specrec = 0;
     int use64 = 0;
+    bool env_no_lean_tails = false, env_force_slots = false, env_debug_overflow = false, env_debug = false;   // read once at create
     int R = 0;          // lean mode tile (no per-barcode slots)
     size_t lds = 0;
     int R_slots = 0;    // slots mode tile (--trim tails, parity dumps)
@@ -134,7 +135,8 @@ struct smx_panel {
     // streams (double-buffered pipelines) each pull tiles from their own queue.
     unsigned *d_tile_counter = nullptr;
     std::mutex tc_mutex;
-    std::vector<void *> tc_streams;
+    std::vector<void *> tc_streams;          // slot -> stream (valid where tc_used)
+    std::vector<char> tc_used;               // a lane gives its slot back when it is destroyed: the next new stream reuses it
     // primer prescan (smx_prescan.hip): bit-sliced HW alignment of every primer over both end windows, run in front of
     // the demux kernel, which then only redoes the alignments the prescan cannot take (smx_prescan_core.h)
     bool pre_ok = false;
@@ -287,6 +289,12 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
             }
     h.bs_ok = bs_ok ? 1 : 0;
     if (const char *e = getenv("SMX_TEST_CAPS")) sscanf(e, "%d,%d", &h.cap_hits, &h.cap_ents);
+    // the remaining test / A-B switches are read here, once: launches never look at the environment
+    h.no_sp = (getenv("SMX_NO_SPECIALISE") ? 1 : 0) | (getenv("SMX_NO_SPECIALISE_NP") ? 2 : 0);
+    P->env_no_lean_tails = getenv("SMX_NO_LEAN_TAILS") != nullptr;
+    P->env_force_slots = getenv("SMX_FORCE_SLOTS") != nullptr;
+    P->env_debug_overflow = getenv("SMX_DEBUG_OVERFLOW") != nullptr;
+    P->env_debug = getenv("SMX_DEBUG") != nullptr;
     h.bs_m = bm[0];
     if (h.pfmin != 0 && h.pfmin < 2) { delete P; return fail(SMX_ERR_UNSUPPORTED, "prefilter min length %d < 2: disable the prefilter", h.pfmin); }
     if (h.bmax + h.kidx > 200) { delete P; return fail(SMX_ERR_UNSUPPORTED, "barcode length + k too large"); }
@@ -351,7 +359,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
         auto pick = [&](size_t bud, int *Rout, size_t *need_out) {
             for (int R = rmax; R >= 1; R >>= 1) {
                 size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, slots,
-                                                  h.bs_ok, 0);
+                                                  h.bs_ok, 0, 2 * NPAIR);
                 if (need <= bud || R == 1) { *Rout = R; *need_out = need; return; }
             }
         };
@@ -373,7 +381,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
         int items = 256;
         if (const char *e = getenv("SMX_COMPACT_ITEMS")) items = std::max(2 * NP, std::min(256, atoi(e)));
         if (P->pre_ok && !(ce && atoi(ce) == 0) && (P->R < 64 || getenv("SMX_COMPACT_ITEMS"))) {
-            auto need_c = [&](int R) { return smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, 0, h.bs_ok, items); };
+            auto need_c = [&](int R) { return smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, 0, h.bs_ok, items, 2 * NPAIR); };
             int best_R = 0, best_blocks = 0;
             size_t best_need = 0;
             for (int R = 64; R >= 8; R -= 8) {
@@ -415,7 +423,7 @@ void smx_panel_destroy(smx_panel *P) {
             for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.1f%%", names[i], tot ? 100.0 * sum[i] / tot : 0.0);
             fprintf(stderr, " (inside the region: scorer wave %.1f%%, first encode wave %.1f%%)", tot ? 100.0 * sum[9] / tot : 0.0, tot ? 100.0 * sum[8] / tot : 0.0);
             fprintf(stderr, "\n");
-            if (getenv("SMX_DEBUG")) {   // where did wave w of each workgroup land?  hist[w][simd]
+            if (P->env_debug) {   // where did wave w of each workgroup land?  hist[w][simd]
                 {
                     unsigned long long worked = 0, launches = 0;
                     for (int b = 0; b < P->phase_grid; b++) { worked += h[(size_t)b * 16 + 14]; }
@@ -466,6 +474,40 @@ int smx_pack_windows(const uint8_t *bases, const uint64_t *offsets, uint32_t n_r
         lens[i] = L;
     }
     return SMX_OK;
+}
+
+// The launch-counter slot of `stream` on this panel (-1: none / no free slot).  claim: take a free slot for a new stream.
+static int stream_slot(smx_panel *P, void *stream, bool claim) {
+    std::lock_guard<std::mutex> g(P->tc_mutex);
+    int free_slot = -1;
+    for (size_t i = 0; i < P->tc_streams.size(); i++) {
+        if (P->tc_used[i] && P->tc_streams[i] == stream) return (int)i;
+        if (!P->tc_used[i] && free_slot < 0) free_slot = (int)i;
+    }
+    if (!claim) return -1;
+    if (free_slot < 0) {
+        if (P->tc_streams.size() == SMX_MAX_STREAMS) return -1;
+        P->tc_streams.push_back(stream);
+        P->tc_used.push_back(1);
+        return (int)P->tc_streams.size() - 1;
+    }
+    P->tc_streams[free_slot] = stream;
+    P->tc_used[free_slot] = 1;
+    return free_slot;
+}
+
+// A stream is going away (synchronised by the caller): its slot -- counters and prescan buffers -- is free for the next one.
+static void stream_release(smx_panel *P, void *stream) {
+    std::lock_guard<std::mutex> g(P->tc_mutex);
+    for (size_t i = 0; i < P->tc_streams.size(); i++)
+        if (P->tc_used[i] && P->tc_streams[i] == stream) P->tc_used[i] = 0;
+}
+
+// After a failed or out-of-step launch on `stream` (already synchronised): re-arm THAT stream's launch counters only.
+// Other lanes of the panel may have kernels in flight on their own slots.
+static void stream_reset_counters(smx_panel *P, void *stream) {
+    const int sl = stream_slot(P, stream, false);
+    if (sl >= 0 && P->d_tile_counter) (void)hipMemset(P->d_tile_counter + 16 * sl, 0, 64);
 }
 
 static int ensure_device(smx_panel *P) {
@@ -525,10 +567,10 @@ static int ensure_device(smx_panel *P) {
         if (smx_prescan_occupancy(P->hp.S, P->pre_mr, P->pre_nx, P->pre_lds, &occ_t, &occ_d) != 0 || occ_t < 1 || occ_d < 1) { occ_t = 1; occ_d = 8; }
         P->pre_blocks_t = occ_t;
         P->pre_blocks_d = occ_d;
-        if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] prescan: transpose %d workgroups/CU (lds %zu), DP %d waves/CU\n", occ_t, P->pre_lds, occ_d);
+        if (P->env_debug) fprintf(stderr, "[smx] prescan: transpose %d workgroups/CU (lds %zu), DP %d waves/CU\n", occ_t, P->pre_lds, occ_d);
     }
     if (const char *e = getenv("SMX_BLOCKS_PER_CU")) P->blocks_per_cu = P->blocks_per_cu_slots = P->blocks_per_cu_c = std::max(1, atoi(e));
-    if (getenv("SMX_DEBUG")) {
+    if (P->env_debug) {
         int occ = -1;
         (void)smx_query_occupancy(&P->hp, P->use64, 0, P->nitems > 0 ? 2 : 0, P->R, 0, P->lds, &occ);
         fprintf(stderr, "[smx] lean R=%d lds=%zu | slots R=%d lds=%zu | occupancy API (lean): %d blocks/CU, grid multiplier %d, CUs %d\n",
@@ -564,20 +606,17 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     // --trim tails when the bit-sliced scan cannot report the tail extent (it can for k <= 3 and at most 32 barcodes
     // per primer).  The hit dump alone (d_hits) comes from whichever kernel the flags select, so that the parity tests
     // see the hit table of the kernel that is benchmarked; its tail_end is defined only where that kernel computes it.
-    const bool lean_tails = P->hp.bs_ok && P->hp.kidx < 4 && P->hp.maxB <= 32 && !getenv("SMX_NO_LEAN_TAILS");
-    const int use_slots = ((P->hp.trim == SMX_TRIM_TAILS && !lean_tails) || d_bdist || getenv("SMX_FORCE_SLOTS")) ? 1 : 0;
+    const bool lean_tails = P->hp.bs_ok && P->hp.kidx < 4 && P->hp.maxB <= 32 && !P->env_no_lean_tails;
+    const int use_slots = ((P->hp.trim == SMX_TRIM_TAILS && !lean_tails) || d_bdist || P->env_force_slots) ? 1 : 0;
     const bool compact = !use_slots && P->nitems > 0 && P->pre_ok;
     const int R = use_slots ? P->R_slots : P->R;
     const size_t lds = use_slots ? P->lds_slots : P->lds;
     unsigned *tc = nullptr;
     size_t slot = 0;
     {
-        std::lock_guard<std::mutex> g(P->tc_mutex);
-        while (slot < P->tc_streams.size() && P->tc_streams[slot] != stream) slot++;
-        if (slot == P->tc_streams.size()) {
-            if (slot == SMX_MAX_STREAMS) return fail(SMX_ERR_UNSUPPORTED, "one panel launched on more than %d streams", SMX_MAX_STREAMS);
-            P->tc_streams.push_back(stream);
-        }
+        int sl = stream_slot(P, stream, true);
+        if (sl < 0) return fail(SMX_ERR_UNSUPPORTED, "one panel launched on more than %d streams at a time", SMX_MAX_STREAMS);
+        slot = (size_t)sl;
         tc = P->d_tile_counter + 16 * slot;
     }
     // primer prescan in front of the demux kernel (same stream: ordered)
@@ -620,7 +659,7 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         const int cgrid = (int)std::min<uint32_t>(ctiles, (uint32_t)(P->n_cu * P->blocks_per_cu_c));
         e = smx_launch_demux(&P->hp, P->use64, P->Rc, cgrid, P->lds_c, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
                              extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, 0, d_pre, npad, &ax);
-        if (e == 0 && getenv("SMX_DEBUG_OVERFLOW")) {   // diagnostic: how many compact tiles went on the overflow list
+        if (e == 0 && P->env_debug_overflow) {   // diagnostic: how many compact tiles went on the overflow list
             unsigned n_ovf = 0;
             (void)hipMemcpyAsync(&n_ovf, tc + 1, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream);
             (void)hipStreamSynchronize((hipStream_t)stream);
@@ -700,7 +739,7 @@ int smx_batch_run(const smx_panel *Pc, const uint8_t *windows, const int32_t *le
     {
         hipError_t se = hipDeviceSynchronize();
         if (se != hipSuccess) {   // an aborted launch leaves the self re-arming counters in an unknown state
-            (void)hipMemset(P->d_tile_counter, 0, 64 * SMX_MAX_STREAMS);
+            stream_reset_counters(P, nullptr);
             return fail(SMX_ERR_DEVICE, "demux kernel failed: %s", hipGetErrorString(se));
         }
     }
@@ -716,12 +755,12 @@ int smx_batch_run(const smx_panel *Pc, const uint8_t *windows, const int32_t *le
     if (c[SMX_CNT_TOTAL] != n_reads) {
         // every read is counted exactly once by the tile that scored it: anything else means tiles were skipped or
         // repeated (a tile queue that did not start at zero) and the records above cannot be trusted
-        (void)hipMemset(P->d_tile_counter, 0, 64 * SMX_MAX_STREAMS);
+        stream_reset_counters(P, nullptr);
         return fail(SMX_ERR_DEVICE, "demux kernel processed %llu of %u reads (tile queue out of step); counters reset",
                     (unsigned long long)c[SMX_CNT_TOTAL], n_reads);
     }
     for (size_t i = 0; i < ncnt; i++) counts[i] += c[i];
-    if (c[SMX_CNT_OVERFLOW]) return fail(SMX_ERR_OVERFLOW, "%llu read(s) produced more than 16 write operations",
+    if (c[SMX_CNT_OVERFLOW]) return fail(SMX_ERR_OVERFLOW, "%llu read(s) produced more than 65535 write operations",
                                          (unsigned long long)c[SMX_CNT_OVERFLOW]);
     if (*n_extra > extra_cap) return fail(SMX_ERR_OVERFLOW, "extra buffer too small: need %u records, have %u", *n_extra, extra_cap);
     return SMX_OK;
@@ -850,7 +889,10 @@ struct smx_lane {
 
 void smx_lane_destroy(smx_lane *L) {
     if (!L) return;
-    if (L->stream) { (void)hipStreamSynchronize(L->stream); }
+    if (L->stream) {
+        (void)hipStreamSynchronize(L->stream);
+        if (L->P) stream_release(L->P, L->stream);   // the panel's per-stream slot (launch counters, prescan buffers) is free again
+    }
     if (L->h_windows) (void)hipHostFree(L->h_windows);
     if (L->h_lens) (void)hipHostFree(L->h_lens);
     if (L->h_ops) (void)hipHostFree(L->h_ops);
@@ -930,14 +972,14 @@ int smx_lane_wait(smx_lane *L, const smx_op **ops, const smx_op **extra, uint32_
     {
         hipError_t se = hipStreamSynchronize(L->stream);
         if (se != hipSuccess) {
-            (void)hipMemset(P->d_tile_counter, 0, 64 * SMX_MAX_STREAMS);
+            stream_reset_counters(P, L->stream);
             return fail(SMX_ERR_DEVICE, "lane batch failed: %s", hipGetErrorString(se));
         }
     }
     const uint32_t ne = (uint32_t)L->h_counts[ncnt];
     *n_extra = ne;
     if (L->h_counts[SMX_CNT_TOTAL] != L->n) {
-        (void)hipMemset(P->d_tile_counter, 0, 64 * SMX_MAX_STREAMS);
+        stream_reset_counters(P, L->stream);
         return fail(SMX_ERR_DEVICE, "demux kernel processed %llu of %u reads (tile queue out of step); counters reset",
                     (unsigned long long)L->h_counts[SMX_CNT_TOTAL], L->n);
     }
@@ -949,7 +991,7 @@ int smx_lane_wait(smx_lane *L, const smx_op **ops, const smx_op **extra, uint32_
     if (ops) *ops = L->h_ops;
     if (extra) *extra = L->h_extra;
     if (L->h_counts[SMX_CNT_OVERFLOW])
-        return fail(SMX_ERR_OVERFLOW, "%llu read(s) produced more than 16 write operations", (unsigned long long)L->h_counts[SMX_CNT_OVERFLOW]);
+        return fail(SMX_ERR_OVERFLOW, "%llu read(s) produced more than 65535 write operations", (unsigned long long)L->h_counts[SMX_CNT_OVERFLOW]);
     return SMX_OK;
 }
 

@@ -45,6 +45,7 @@ struct DevPanel {
     // bs_re[((p * 16 + row) * 16 + code) * MBW + w] = bitmask over primer p's barcode list: barcode_rc[row] eq code
     int bs_ok, bs_m;
     int cap_hits, cap_ents;   // test hook (SMX_TEST_CAPS=h,e): force small barcode rounds; 0 = default sizing
+    int no_sp;                // SMX_NO_SPECIALISE (bit 0) / SMX_NO_SPECIALISE_NP (bit 1), read once at smx_panel_create
     const unsigned *bs_re;
     unsigned long long *dbg_phase;        // SMX_PHASE_TIMING=1: [grid][16] cycle sums per phase (diagnostic build-in)
 };
@@ -75,7 +76,7 @@ int smx_prescan_set_lds_limit(size_t bytes);
 int smx_prescan_occupancy(int S, int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d);
 int smx_prescan_transpose_threads(int S);
 size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta, int kidx,
-                           int slots, int bs, int nitems);
+                           int slots, int bs, int nitems, int ncand);
 int smx_set_demux_lds_limit(int use64, size_t bytes);
 int smx_query_occupancy(const smx::DevPanel *P, int use64, int use_slots, int cm, int R, int nitems, size_t lds_bytes,
                         int *blocks_per_cu);

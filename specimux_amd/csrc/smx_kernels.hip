@@ -121,7 +121,6 @@ struct HitL {
 };
 static_assert(sizeof(HitL) == 16, "HitL layout");
 
-#define SMX_MAX_EMIT 16
 struct TileLayout {   // byte offsets into dynamic LDS
     int tacc, ppeq, prpeq, bpeq, bsre, lut, pmeta, codes, namask, lens, ocnt, rflag, hits, masks, tiem, bres, dmask, ents, offsA, offsB, queue, emit, opsL, aggr, etail,
         hmap, clist, pmask, hcand, total;
@@ -149,7 +148,7 @@ static_assert(sizeof(EntL) == 12, "EntL layout");
 
 template <typename PW>
 __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, int maxB, int need_starts,
-                                                    int npmeta, int kidx, int slots, int bs, int cap_hits = 0,
+                                                    int npmeta, int kidx, int slots, int bs, int ncand, int cap_hits = 0,
                                                     int cap_ents = 0, int nitems = 0) {
     // nitems > 0: compact mode.  The tile keeps per-alignment state (hit record, end mask, scan slots) for at most nitems
     // of its R * H alignments -- the ones the prescan's match words flag -- plus one shared "no match" record; hmap maps
@@ -195,7 +194,7 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.tiem = o;  o += (t.NI + sentinel) * t.MBW * 4;
     t.clist = o; o += nitems > 0 ? ((t.NI + 1) & ~1) * 2 : 0;       // record -> read * H + alignment
     // time-shared regions: {location entries} are dead after the barcode scan -> staged result records;
-    // {primer end masks, scans, queue} are dead once the scorer starts -> its emission log
+    // {primer end masks, scans, queue} are dead once the scorer starts -> its per-(read, candidate) trim shifts (Q8)
     t.bres = t.dmask = o; o += slots ? t.CAPH * t.G * 4 : t.CAPH * (kidx + 1) * t.MBW * 4;
     {
         int c = t.CAPE * (int)sizeof(EntL), d = R * 32;
@@ -207,7 +206,7 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.offsA = o; o += (t.NI + 1) * 4;
     t.offsB = o; o += (t.NI + 1) * 4;
     t.queue = o; o += ((t.NI + 1) & ~1) * 2;
-    if (o < t.emit + R * SMX_MAX_EMIT * 4) o = t.emit + R * SMX_MAX_EMIT * 4;
+    if (o < t.emit + R * ncand * 4) o = t.emit + R * ncand * 4;
     o = (o + 7) & ~7;
     t.hmap = o;  o += nitems > 0 ? ((R * H + 1) & ~1) * 2 : 0;     // (read, alignment) -> record; t.NI = the shared "no match" record
     o = (o + 7) & ~7;
@@ -672,7 +671,7 @@ struct Emitter {
     unsigned extra_cap;
     unsigned *n_extra;
     unsigned long long *counts;
-    unsigned *emitlog;         // LDS: SMX_MAX_EMIT entries of (cand_id << 16 | s) ... s stored separately below
+    int *cum;                  // LDS, one int per candidate of this read: the trim shift its earlier emissions have added up (Q8)
     int *aggr;                 // LDS block aggregates
     unsigned read;
     int n;                     // ops emitted so far
@@ -702,19 +701,15 @@ __device__ inline void emit_op(Emitter &E, const CandView *v, int cand_id, int s
     bool fallback = false;
     if (c.trim != SMX_TRIM_NONE) {
         if (v) {
-            int cum = 0;   // Q8: the same CandidateMatch emitted earlier already had its locations shifted
-            int nlog = E.n < SMX_MAX_EMIT ? E.n : SMX_MAX_EMIT;
-            for (int i = 0; i < nlog; i++) {
-                unsigned w = E.emitlog[i];
-                if ((int)(w >> 24) == cand_id) cum += (int)(w & 0xFFFFFFu) - 0x800000;
-            }
+            // Q8: the same CandidateMatch emitted earlier already had its locations shifted by the trim start of each of
+            // those emissions.  One running sum per candidate: any number of emissions per read (a tie storm at a large
+            // index distance emits one record per tied specimen, hundreds for one read).
+            const int cum = E.cum[cand_id];
             cand_extent(c, *v, cum, s, e);
+            if (s < e) E.cum[cand_id] = cum + s;
         }
         if (s >= e) { fallback = true; s = 0; e = c.L; }   // Q12
     }
-    if (E.n < SMX_MAX_EMIT)
-        E.emitlog[E.n] = ((unsigned)(cand_id & 0xFF) << 24) |
-                         (unsigned)(((v && c.trim != SMX_TRIM_NONE && !fallback) ? s : 0) + 0x800000);
     op.trim_start = s;
     op.trim_end = e;
     if (fallback) {
@@ -738,7 +733,7 @@ __device__ inline void emit_op(Emitter &E, const CandView *v, int cand_id, int s
         if (slot < E.extra_cap) E.extra[slot] = op;
     }
     E.n++;
-    if (E.n > SMX_MAX_EMIT || cand_id > 255) E.overflow = true;
+    if (E.n > 0xFFFF) E.overflow = true;   // n_ops is 16 bits wide
 }
 
 // resolve_specimen for a non-full candidate (demultiplex.py:576-589) -> emits.
@@ -1115,7 +1110,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     const int use_slots = SP != 0 ? 0 : use_slots_arg;
     int8_t *const dbg_bdist = SP != 0 ? nullptr : dbg_bdist_arg;
     const int use_bs = SP != 0 ? 1 : ((BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0);
-    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, need_starts, npmeta, sp ? 3 : P->kidx, use_slots, P->bs_ok,
+    const int ncand = 2 * NPAIR;
+    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, need_starts, npmeta, sp ? 3 : P->kidx, use_slots, P->bs_ok, ncand,
                                          sp ? 0 : P->cap_hits, sp ? 0 : P->cap_ents, (sp && CM == 1) ? 256 : aux.nitems);
     // compact mode (aux.nitems > 0, lean launches of many-primer panels behind the prescan): records only for the
     // alignments the prescan's match words flag; a tile with more flagged alignments than records is put on the
@@ -1142,7 +1138,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
     int *offsA = (int *)(lds + T.offsA);    // exclusive scan of searched locations per hit
     int *offsB = (int *)(lds + T.offsB);    // exclusive scan of searched hits (rank)
     unsigned short *queue = (unsigned short *)(lds + T.queue);   // rank -> hit
-    unsigned *emitlog = (unsigned *)(lds + T.emit);
+    int *cumL = (int *)(lds + T.emit);      // scorer: [read][candidate] accumulated trim shift
     smx_op *opsL = (smx_op *)(lds + T.opsL);
     int *aggr = (int *)(lds + T.aggr);      // [0..7] counters, [8] round end rank, [9] next tile, [10] fallback items, [11] flagged alignments
     unsigned short *hmap = (unsigned short *)(lds + T.hmap);     // compact mode: read * H + alignment -> record (T.NI = "no match")
@@ -1307,12 +1303,6 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             PW Pvv = ~(PW)0, Mv = 0;
             int score = m, best = m + 1, jstar = 0, cnt = 0;
             unsigned *mrow = masks + __mul24(item, MW);
-#if defined(SMX_EXP) && SMX_EXP == 7
-            g.Sp = 0; g.j_lo = 1;   // timing experiment: no primer columns
-#endif
-#if defined(SMX_EXP) && SMX_EXP == 8
-            if (!use_pre) { g.Sp = 0; g.j_lo = 1; }   // timing experiment: the fallback pass scans no columns (short reads never match)
-#endif
             // With the prescan: its flag words cover the window's first Sp columns = the whole stored window, which is the
             // primer target unless the read is shorter than search_len AND its target starts inside the window
             // (g.j_lo > 0): then only the orientation vote comes from the prescan (determine_orientation looks
@@ -1616,9 +1606,6 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             nq = offsB[nI];
             __syncthreads();
         }
-#if defined(SMX_EXP) && SMX_EXP == 6
-        nq = 0;   // instruction-count experiment: no barcode work at all
-#endif
         STAMP(2);
 
         // ---- phase 3b/3c in rounds of at most CAPH searched hits and CAPE (hit, location) entries
@@ -1892,6 +1879,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
         // the encode target buffers: namask is OR-ed into, the next tile's orientation votes are counted up
         for (int i = tid; i < R * 2 * MW; i += NT) namask[i] = 0;
         for (int i = tid; i < R; i += NT) { ocnt[(par ^ 1) * R + i] = 0; rflag[(par ^ 1) * R + i] = 0; }
+        if (live) for (int i = tid; i < nr * ncand; i += NT) cumL[i] = 0;   // (the masks / scan arrays it overlays are dead by now)
         if (tid == 0) { aggr[9] = (int)popped; aggr[11] = 0; }
         __syncthreads();
         const uint32_t nxt = (uint32_t)aggr[9];
@@ -1937,7 +1925,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     Emitter E;
                     E.c = &c; E.primary = opsL + r; E.extra = extra; E.extra_cap = extra_cap;
                     E.n_extra = tile_counter + 3;   // see the kernel's epilogue
-                    E.counts = counts; E.emitlog = emitlog + r * SMX_MAX_EMIT; E.aggr = aggr; E.read = r0 + r;
+                    E.counts = counts; E.cum = cumL + r * ncand; E.aggr = aggr; E.read = r0 + r;
                     E.n = 0; E.matched = false; E.overflow = false;
                     const bool done = score_fast(E, ori, sub, G);
                     if (sub == 0) {
@@ -2211,11 +2199,11 @@ int demux_bsv(const smx::DevPanel *P, int use_slots) {
 int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm, int R, int nitems) {
     const bool flags = !use64 && bsv == 1 && cm != 2 && (cm == 0 || nitems == 256) && !P->cap_hits && !P->cap_ents &&
                        P->kidx == 3 && P->maxB <= 32 && !P->need_starts && P->trim == SMX_TRIM_BARCODES && P->derep == SMX_DEREP_BEST &&
-                       P->preorient && P->minlen == -1 && P->maxlen == -1 && !P->dbg_phase && !getenv("SMX_NO_SPECIALISE");
+                       P->preorient && P->minlen == -1 && P->maxlen == -1 && !P->dbg_phase && !(P->no_sp & 1);
     if (!flags) return 0;
     if (P->S == 160 && R == 32 && cm == 1) return 3;                       // wide windows, compact 32-read tiles
     if (P->S != 80 || R != 64) return 0;
-    return (cm == 0 && P->NP == 2 && P->NPAIR == 1 && !getenv("SMX_NO_SPECIALISE_NP")) ? 2 : 1;
+    return (cm == 0 && P->NP == 2 && P->NPAIR == 1 && !(P->no_sp & 2)) ? 2 : 1;
 }
 }  // namespace
 
@@ -2244,9 +2232,9 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
 }
 
 extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta,
-                                      int kidx, int slots, int bs, int nitems) {
-    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, 0, 0, nitems).total
-                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, 0, 0, nitems).total;
+                                      int kidx, int slots, int bs, int nitems, int ncand) {
+    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, ncand, 0, 0, nitems).total
+                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, ncand, 0, 0, nitems).total;
 }
 
 extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {

@@ -42,42 +42,88 @@ def stride_batches(reader, rank, world, batch_reads, batch_bytes=0):
         i += 1
 
 
-def merge_rank_trees(output_dir, world, keep=()):
-    """Rank 0, after the barrier: append every file of <output_dir>/.smx_rank_<k>/ (k ascending = file order of the
-    input, so each merged file holds its records in input order exactly like a single-process run) to the same relative
-    path under output_dir, then remove the rank trees.  The analogue of the reference's workers appending to shared
-    files under a lock (io_utils.py:108-121), done once instead of per record."""
-    import shutil
-    n_files = 0
-    for k in range(world):
-        root = rank_dir(output_dir, k)
+def _append_file(src, dst_fd):
+    """Append the whole of `src` to the open descriptor `dst_fd` inside the kernel when the platform allows it."""
+    with open(src, "rb") as fh:
+        left = os.fstat(fh.fileno()).st_size
+        try:
+            while left > 0:
+                n = os.sendfile(dst_fd, fh.fileno(), None, min(left, 1 << 30))
+                if n == 0:
+                    break
+                left -= n
+        except OSError:   # sendfile not available for this pair of files: plain copy of what is left
+            while True:
+                buf = fh.read(8 << 20)
+                if not buf:
+                    break
+                os.write(dst_fd, buf)
+
+
+def merge_rank_trees(output_dir, world, rank=0, n_mergers=1, keep=()):
+    """After the barrier that says every rank's tree is complete and closed, EVERY rank calls this with its own rank and
+    n_mergers = world: merger r owns the output files whose relative path hashes to r and builds each of them from the rank
+    trees <output_dir>/.smx_rank_<k>/ in ascending k (= file order of the input under byte-range sharding, so a merged
+    file holds its records in input order exactly like a single-process run).  The first piece of a file that does not
+    exist yet is renamed into place (same file system: no bytes move), the others are appended with sendfile.  The
+    analogue of the reference's workers appending to shared files under a per-file lock (io_utils.py:108-121), done once
+    per file instead of once per record, and in parallel over the files.  Returns the number of files this caller built.
+    The rank trees themselves are removed by their owners afterwards (remove_rank_tree)."""
+    import zlib
+    roots = [rank_dir(output_dir, k) for k in range(world)]
+    rels = set()
+    for root in roots:
         if not os.path.isdir(root):
             continue
-        for dirpath, _dirs, files in sorted(os.walk(root)):
-            for fn in sorted(files):
-                if fn in keep:
-                    continue
-                src = os.path.join(dirpath, fn)
-                dst = os.path.join(output_dir, os.path.relpath(src, root))
-                os.makedirs(os.path.dirname(dst), exist_ok=True)
-                with open(src, "rb") as a, open(dst, "ab") as b:
-                    shutil.copyfileobj(a, b, 8 << 20)
-                n_files += 1
-        shutil.rmtree(root, ignore_errors=True)
+        for dirpath, _dirs, files in os.walk(root):
+            for fn in files:
+                if fn not in keep:
+                    rels.add(os.path.relpath(os.path.join(dirpath, fn), root))
+    n_files = 0
+    for rel in sorted(rels):
+        if zlib.crc32(rel.encode()) % n_mergers != rank:
+            continue
+        dst = os.path.join(output_dir, rel)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        srcs = [os.path.join(root, rel) for root in roots if os.path.exists(os.path.join(root, rel))]
+        if not os.path.exists(dst):
+            os.rename(srcs[0], dst)
+            srcs = srcs[1:]
+        if srcs:
+            fd = os.open(dst, os.O_WRONLY | os.O_APPEND)
+            try:
+                for s in srcs:
+                    _append_file(s, fd)
+            finally:
+                os.close(fd)
+        n_files += 1
     return n_files
+
+
+def remove_rank_tree(output_dir, rank):
+    import shutil
+    shutil.rmtree(rank_dir(output_dir, rank), ignore_errors=True)
 
 
 def rank_dir(output_dir, rank):
     return os.path.join(output_dir, f".smx_rank_{rank}")
 
 
-def run_sharded(sequence_file, output_dir, prefix, counts_len, shard_runner, backend=None):
+ST_OK, ST_CANNOT_CUT, ST_ERROR = 0, 1, 2
+
+
+def run_sharded(sequence_file, output_dir, prefix, counts_len, shard_runner, backend=None, window=None):
     """One input file over WORLD_SIZE processes (one per GPU, launched by torch.distributed.run before anything touches
     a GPU).  Rank k demultiplexes the records that start inside its byte range into its own tree
     (`shard_runner(sequence_file, rank_output_dir, byte_range, stride) -> (total, matched, counts uint64[counts_len])`;
-    `stride` = (rank, world) instead of a byte range when the file cannot be cut), the counts vectors are summed over
-    the ranks with one all-reduce (RCCL through the C ABI on GPUs), rank 0 merges the trees.
-    Returns (global total, global matched, global counts, world) on every rank."""
+    `stride` = (rank, world) instead of a byte range when the file cannot be cut -- gzip, FASTA, wrapped FASTQ -- or when
+    the run is restricted to a record window, `window` = True: -n start,num counts records from the start of the file,
+    which only a reader of the whole file can do), the counts vectors are summed over the ranks with one all-reduce
+    (RCCL through the C ABI on GPUs), and all ranks merge the trees in parallel (merge_rank_trees).
+    A failure on one rank is agreed on by all ranks (one MAX all-reduce of a status word) before anybody raises, so no
+    rank is left waiting in a collective.  Returns (global total, global matched, global counts, world) on every rank."""
+    import glob
+    import shutil
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -91,31 +137,50 @@ def run_sharded(sequence_file, output_dir, prefix, counts_len, shard_runner, bac
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
+    dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+
+    def agree(code):
+        """The worst status over all ranks."""
+        flag = torch.tensor([code], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return int(flag.item())
+
+    def attempt(byte_range, stride):
+        """-> (status, result or exception): every exception is caught so that the ranks can agree on what to do next."""
+        from . import _lib
+        try:
+            return ST_OK, shard_runner(sequence_file, out, byte_range, stride)
+        except _lib.SmxError as e:
+            return (ST_CANNOT_CUT if (byte_range is not None and e.code == _lib.ERR_UNSUPPORTED) else ST_ERROR), e
+        except Exception as e:   # noqa: BLE001 -- re-raised after the collective
+            return ST_ERROR, e
+
     try:
         if on_gpu:
             from . import _lib
             _lib.check(_lib.load().smx_device_init(local_rank if backend == "nccl" else 0, None))
-        size = os.path.getsize(sequence_file)
-        byte_range, stride = shard_range(size, rank, world), None
+        # stale rank trees of a killed earlier run must not be merged into this one (the writers append)
+        if rank == 0:
+            for stale in glob.glob(os.path.join(output_dir, ".smx_rank_*")):
+                shutil.rmtree(stale, ignore_errors=True)
+        dist.barrier()
         out = rank_dir(output_dir, rank)
         os.makedirs(out, exist_ok=True)
-        try:
-            total, matched, counts = shard_runner(sequence_file, out, byte_range, None)
-            cut_ok = 1
-        except Exception as e:   # not an uncompressed 4-line FASTQ: every rank must switch, or none
-            if "byte range" not in str(e):
-                raise
-            cut_ok = 0
-        flag = torch.tensor([cut_ok], dtype=torch.int32, device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            import shutil
+        size = os.path.getsize(sequence_file)
+        status, res = (ST_CANNOT_CUT, None) if window else attempt(shard_range(size, rank, world), None)
+        worst = agree(status)
+        if worst == ST_CANNOT_CUT:   # every rank switches to batch striding, or none
             shutil.rmtree(out, ignore_errors=True)
             os.makedirs(out, exist_ok=True)
-            stride = (rank, world)
-            total, matched, counts = shard_runner(sequence_file, out, None, stride)
+            status, res = attempt(None, (rank, world))
+            worst = agree(status)
+        if worst != ST_OK:
+            shutil.rmtree(out, ignore_errors=True)
+            if status != ST_OK:
+                raise res
+            raise RuntimeError("another rank failed while demultiplexing its shard (see its message)")
+        total, matched, counts = res
         assert len(counts) == counts_len
-        dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
         t = torch.from_numpy(np.ascontiguousarray(counts).astype(np.int64)).to(dev)
         reducer = CountsReducer(world, rank, "rccl" if backend == "nccl" else "torch")
         reducer.allreduce_(t)
@@ -124,8 +189,9 @@ def run_sharded(sequence_file, output_dir, prefix, counts_len, shard_runner, bac
         reducer.close()
         gcounts = t.cpu().numpy().astype(np.uint64)
         dist.barrier()          # every rank's tree is complete and closed
-        if rank == 0:
-            merge_rank_trees(output_dir, world)
+        merge_rank_trees(output_dir, world, rank, world)
+        dist.barrier()          # every output file is complete
+        remove_rank_tree(output_dir, rank)
         dist.barrier()
         return int(gcounts[0]), int(gcounts[1]), gcounts, world
     finally:

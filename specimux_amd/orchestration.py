@@ -233,19 +233,22 @@ def _run_native(args):
     if world > 1:
         # one process per GPU (python -m torch.distributed.run ... -m specimux_amd.cli ...): the input file is cut
         # into byte ranges at record boundaries, every rank writes its own tree, one RCCL all-reduce sums the counts,
-        # rank 0 merges (specimux_amd/distributed.py; reference: the worker pool of orchestration.py:181-207)
-        if args.start_seq > 1 or args.num_seqs >= 0:
-            raise ValueError("-n/--num-seqs windows are not supported together with multi-GPU sharding")
+        # all ranks merge (specimux_amd/distributed.py; reference: the worker pool of orchestration.py:181-207).
+        # -n start,num (cli.py:54-68, orchestration.py:170-172) counts records from the start of the file: every rank then
+        # reads the whole file, applies the window, and keeps batch i iff i mod world == rank (batch striding).
         from .distributed import run_sharded
+        window = args.start_seq > 1 or args.num_seqs >= 0
 
         def shard_runner(seqfile, out_dir, byte_range, stride):
-            t, m, c, _fq = run_streaming(seqfile, panel, out_dir, args.output_file_prefix, byte_range=byte_range, stride=stride)
+            t, m, c, _fq = run_streaming(seqfile, panel, out_dir, args.output_file_prefix, byte_range=byte_range, stride=stride,
+                                         start_seq=args.start_seq if window else 1, num_seqs=args.num_seqs if window else -1)
             return t, m, c
 
         total, matched, _counts, _w = run_sharded(args.sequence_file, args.output_dir, args.output_file_prefix,
-                                                  panel.counts_len, shard_runner)
+                                                  panel.counts_len, shard_runner, window=window)
         if rank == 0:
-            logging.info(f"Demultiplexed on {world} GPUs (read-sharded by byte range, counts summed by all-reduce)")
+            logging.info(f"Demultiplexed on {world} GPUs (read-sharded by " + ("batch striding inside the -n window" if window
+                         else "byte range") + ", counts summed by all-reduce)")
             _finish(total, matched, start)
             cleanup_empty_directories(args.output_dir)
             if getattr(args, "sample_topq", 0) > 0:
@@ -307,11 +310,25 @@ def _run_records(args, to_files: bool):
         cleanup_locks(args.output_dir)
 
 
+def _only_rank0_runs(what: str) -> bool:
+    """The record path (trace logging, stdout mode) is one stream of records through one process: under a
+    one-process-per-GPU launch rank 0 runs it alone and the other ranks leave at once -- otherwise every rank would push
+    the whole input through, append to the same files and write trace files under the same worker id.
+    Returns True when this process should return without doing anything."""
+    from .distributed import env_rank
+    rank, _local, world = env_rank()
+    if world > 1 and rank == 0:
+        logging.warning(f"{what} runs on one GPU: ranks 1..{world - 1} of this launch stay idle")
+    return world > 1 and rank > 0
+
+
 def specimux_mp(args):
     """File-output entry (`-F`).  The reference forks a worker pool here; the GPU path needs no host
     parallelism for the matching itself."""
     if getattr(args, "diagnostics", None):
         # trace events are attached to record objects: the record path (Python parser) carries them
+        if _only_rank0_runs("-F with -d (trace logging)"):
+            return
         _run_records(args, to_files=True)
         return
     _run_native(args)
@@ -319,4 +336,6 @@ def specimux_mp(args):
 
 def specimux(args):
     """stdout entry (no `-F`)."""
+    if _only_rank0_runs("stdout mode"):
+        return
     _run_records(args, to_files=False)

@@ -180,6 +180,33 @@ class ReadSet:
             for i, (s, q) in enumerate(zip(self.reads, self.quals)):
                 fh.write(f"@read{i:07d} synthetic\n{s}\n+\n{q}\n")
 
+    def write_fastq_rebuilt(self, path, S, seed=0):
+        """FASTQ of a windows-only set: read i = rebuild_read(head, tail, len) (filler in the middle), quality = a slice of
+        one random Phred block.  Byte-level loop, ~10^6 reads in seconds: the end-to-end bench's input file."""
+        n = len(self.lens)
+        hb, tb = np.ascontiguousarray(self.head).tobytes(), np.ascontiguousarray(self.tail).tobytes()
+        W = self.head.shape[1]
+        lens = self.lens.tolist()
+        maxL = max(lens) if lens else 0
+        qblock = (np.random.default_rng(seed).integers(3, 41, maxL + 4096) + 33).astype(np.uint8).tobytes()
+        filler = b"A" * maxL
+        with open(path, "wb") as fh:
+            for lo in range(0, n, 8192):
+                parts = []
+                for i in range(lo, min(n, lo + 8192)):
+                    L = lens[i]
+                    Sp = S if L > S else L
+                    h = hb[i * W:i * W + Sp]
+                    if L <= S:
+                        s = h
+                    elif L < 2 * S:
+                        s = h + tb[i * W + 2 * S - L:i * W + Sp]
+                    else:
+                        s = h + filler[:L - 2 * S] + tb[i * W:i * W + Sp]
+                    off = i & 4095
+                    parts.append(b"@read%07d synthetic\n%b\n+\n%b\n" % (i, s, qblock[off:off + L]))
+                fh.write(b"".join(parts))
+
 
 CHUNK = 65536   # part of the generator's definition: chunk c of a read set uses default_rng([seed, c])
 

@@ -152,3 +152,38 @@ def test_two_rank_file_path_equals_single_process(tmp_path, kind):
         n_rec = path.read_text().count("\n") // 4 if path.exists() else 0
         assert int(g0[_lib.CNT_SPECIMEN0 + i]) == n_rec, spec[0]
     assert int(g0[_lib.CNT_SPECIMEN0:].sum()) > 500
+
+
+def test_parallel_merge_equals_rank_order_concatenation(tmp_path):
+    """merge_rank_trees split over three mergers (what the three ranks do after the barrier): every output file is the
+    concatenation of the rank trees' files in rank order, whoever built it; a file that existed before is appended to;
+    every file is built by exactly one merger."""
+    from specimux_amd.distributed import merge_rank_trees, rank_dir, remove_rank_tree
+    out = tmp_path / "out"
+    world = 3
+    expect = {}
+    rng = np.random.default_rng(5)
+    names = [f"full/P/spec{i}.fastq" for i in range(40)] + [f"partial/P/a-b/x{i}.fastq" for i in range(25)] + ["unknown/u.fastq"]
+    (out / "full" / "P").mkdir(parents=True)
+    (out / "full" / "P" / "spec3.fastq").write_text("@old\nAC\n+\nII\n")      # left by an earlier run: appended to
+    expect["full/P/spec3.fastq"] = "@old\nAC\n+\nII\n"
+    for k in range(world):
+        for nm in names:
+            if rng.random() < 0.6 or nm == "unknown/u.fastq":
+                path = os.path.join(rank_dir(os.fspath(out), k), nm)
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                text = "".join(f"@r{k}_{j}\nACGT\n+\nIIII\n" for j in range(int(rng.integers(1, 50))))
+                with open(path, "w") as fh:
+                    fh.write(text)
+                expect[nm] = expect.get(nm, "") + text
+    built = [merge_rank_trees(os.fspath(out), world, r, world) for r in range(world)]
+    for r in range(world):
+        remove_rank_tree(os.fspath(out), r)
+    got = {}
+    for dirpath, _d, files in os.walk(out):
+        for fn in files:
+            full = os.path.join(dirpath, fn)
+            got[os.path.relpath(full, out)] = open(full).read()
+    assert got == expect
+    assert sum(built) == len(expect) and min(built) > 0
+    assert not any(p.name.startswith(".smx_rank_") for p in out.iterdir())

@@ -250,20 +250,13 @@ def test_flag_matrix(lib, c2, flags):
     reads = reads_from_set(rs, range(400), S_)
     both = Both(pf, sf, **flags)
     both.assert_hits_equal(reads[:60], str(flags))
+    got = both.assert_ops_equal(reads, str(flags))
     if flags.get("index_edit_distance", 0) >= 6:
-        # k ~ half the barcode length: a few reads tie with dozens of barcodes and yield more write operations than the
-        # kernel keeps per read (16, include/smx.h SMX_ERR_OVERFLOW: reported, never dropped silently).  Those reads
-        # must make the batch fail loudly; every other read is compared as usual.
+        # k ~ half the barcode length: a few reads tie with dozens of barcodes and the reference writes one record per
+        # tied specimen (demultiplex.py:434-436, Q9) -- far more than 16 per read.  The kernel keeps one running trim shift
+        # per candidate instead of a bounded emission log, so those reads come out record for record like any other.
         from collections import Counter
-        from specimux_amd import _lib
-        n_ops = Counter(k[0] for k in both.oracle_ops(reads)[0])
-        big = {rid for rid, c in n_ops.items() if c > 16}
-        assert len(big) <= len(reads) // 50
-        if big:
-            with pytest.raises(_lib.SmxError, match="more than 16 write operations"):
-                both.product_ops(reads)
-        reads = [r for r in reads if r[0] not in big]
-    both.assert_ops_equal(reads, str(flags))
+        assert max(Counter(k[0] for k in got).values()) > 16
     # the golden reads too (real ONT data, gITS7 has IUPAC R)
     gold = Both(P, S, **flags)
     gold.assert_ops_equal(golden_reads("sequences.fastq"), f"golden {flags}")
@@ -605,10 +598,10 @@ def test_cli_two_rank_launch_equals_single_process(lib, c2, tmp_path):
 
 
 # ------------------------------------------------------------------ panel shapes that select other kernel paths
-def _custom_panel(tmp_path_factory, name, n_fwd, n_rev, bc_len, min_dist, fwd_primer=None, mixed=False, seed=7):
+def _custom_panel(tmp_path_factory, name, n_fwd, n_rev, bc_len, min_dist, fwd_primer=None, mixed=False, seed=7, rev_primer=None):
     from specimux_amd import synth
     f, r = synth.make_barcodes(n_fwd, n_rev, length=bc_len, min_dist=min_dist, seed=seed)
-    pools = [("ITS", "FWD", fwd_primer or synth.ITS1F, "ITS4", synth.ITS4)]
+    pools = [("ITS", "FWD", fwd_primer or synth.ITS1F, "ITS4", rev_primer or synth.ITS4)]
     pan = synth.Panel(pools, f, r)          # the reads are generated from the uniform panel
     files = pan
     if mixed:   # the panel FILE gets one shorter forward barcode: mixed lengths (the prefilter must then be off)
@@ -616,12 +609,25 @@ def _custom_panel(tmp_path_factory, name, n_fwd, n_rev, bc_len, min_dist, fwd_pr
     return pan, tmp_panel(tmp_path_factory, files, name)
 
 
+# primer lengths that select the other instantiations of the prescan DP kernel (prescan_dp_kernel<rows, extra symbols, *>,
+# smx_prescan.hip SMX_PRE_VARIANTS): rows 22 (<= 22 nt), 24 (23-24 nt), 31 (25-31 nt) x all-ACGT / degenerate letters
+PRIMER_SHAPES = {
+    "24nt_acgt_primer": "CTTGGTCATTTAGAGGAAGTAAAA",              # -> <24, 0>
+    "28nt_acgt_primer": "CTTGGTCATTTAGAGGAAGTAAAAGTCG",          # -> <31, 0>
+    "31nt_acgt_primer": "CTTGGTCATTTAGAGGAAGTAAAAGTCGTAA",       # -> <31, 0>, every row live
+    "28nt_degenerate_primer": "CTTGGTCATYTAGAGGARGTAAAAGTCG",    # -> <31, 4>
+    "20nt_degenerate_primer": "GAYGAYMGWGATCAYTTYGG",            # -> <22, 4>
+}
+
+
 @pytest.mark.parametrize("shape", ["96x4_multiword", "24nt_barcodes", "40nt_primer_64bit", "mixed_lengths",
                                    "8nt_barcodes", "10nt_barcodes", "16nt_barcodes", "16nt_barcodes_k4",
-                                   "16nt_barcodes_k6", "8nt_barcodes_k4", "96x4_multiword_k5"])
-def test_panel_shapes(lib, tmp_path_factory, shape):
+                                   "16nt_barcodes_k6", "8nt_barcodes_k4", "96x4_multiword_k5", "40nt_primer_64bit_k5"]
+                         + sorted(PRIMER_SHAPES))
+def test_panel_shapes(lib, tmp_path_factory, monkeypatch, shape):
     from specimux_amd import synth
     flags = {}
+    name = shape
     if "_k" in shape:   # bitsliced_shw_pad<4,16> (16 nt, k = 4), the generic scan at other heights / word counts
         flags = dict(index_edit_distance=int(shape.rsplit("_k", 1)[1]))
         shape = shape.rsplit("_k", 1)[0]
@@ -633,6 +639,8 @@ def test_panel_shapes(lib, tmp_path_factory, shape):
     elif shape == "40nt_primer_64bit":  # primer longer than 32 nt: 64-bit primer words
         pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 8, 6, 13, 6,
                                       fwd_primer="CTTGGTCATTTAGAGGAAGTAAAAGTCGTAACAAGGTTTCC")
+    elif shape in PRIMER_SHAPES:
+        pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 8, 6, 13, 6, fwd_primer=PRIMER_SHAPES[shape])
     elif shape.endswith("nt_barcodes"):   # the padded bit-sliced scan's other heights: M = 8, 12, 16 rows
         n = int(shape.split("nt")[0])
         pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 8, 6, n, {8: 4, 10: 5, 16: 7}[n])
@@ -643,9 +651,18 @@ def test_panel_shapes(lib, tmp_path_factory, shape):
     reads = reads_from_set(rs, range(500), 80)
     for fl in (flags, dict(flags, trim="tails")):
         both = Both(pf, sf, **fl)
-        both.assert_hits_equal(reads[:80], f"{shape} {fl}")
-        got = both.assert_ops_equal(reads, f"{shape} {fl}")
+        both.assert_hits_equal(reads[:80], f"{name} {fl}")
+        got = both.assert_ops_equal(reads, f"{name} {fl}")
         assert sum(1 for k in got if k[6] == "DEREP") > 100
+    if name in PRIMER_SHAPES:
+        # the same DP kernel with the match words compiled in (<rows, symbols, 1>: what panels with compact demux tiles run),
+        # compact tiles forced on, with a capacity that sends part of the tiles through the overflow list; short reads too
+        monkeypatch.setenv("SMX_COMPACT_ITEMS", "120")
+        short = synth.make_reads(pan, 100, 98, insert_mean=40, insert_sd=30, windows_only=False)
+        reads2 = reads[:300] + reads_from_set(short, range(100), 80, prefix="s")
+        both = Both(pf, sf, **flags)
+        both.assert_hits_equal(reads2[:60] + reads2[-40:], f"{name} compact", lean=True)
+        both.assert_ops_equal(reads2, f"{name} compact")
 
 
 def test_forced_small_barcode_rounds(c2, monkeypatch):
@@ -741,3 +758,155 @@ def test_compact_tiles_other_scan_variants(lib, tmp_path_factory, monkeypatch, s
             both.assert_hits_equal(reads[:100], f"compact {shape} {fl} {items}", lean=True)
             got = both.assert_ops_equal(reads, f"compact {shape} {fl} {items}")
             assert sum(1 for k in got if k[6] == "DEREP") > 100
+
+
+# ------------------------------------------------------------------ randomised evidence inside the suite
+FUZZ_FLAG_SETS = [dict(), dict(trim="tails"), dict(trim="primers"), dict(dereplicate="none"), dict(disable_prefilter=True),
+                  dict(disable_preorient=True), dict(search_len=64), dict(search_len=120), dict(index_edit_distance=2),
+                  dict(primer_edit_distance=4), dict(index_edit_distance=4, disable_prefilter=True),
+                  dict(search_len=160, error_rate=0.12, n_frac=0.05), dict(search_len=48, n_frac=0.1), dict(search_len=96, trim="tails")]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_bounded_fuzz(lib, c1, c2, c3, seed):
+    """The manual fuzz loop (tests/fuzz_parity.py), bounded: fixed seeds, the three panels in rotation over 14 flag sets
+    (search lengths on both sides of the prescan's multiple-of-16 rule, N reads, high error rates, every trim / dereplicate
+    mode), records of every read and hit tables of a sample against the oracle."""
+    from specimux_amd import synth
+    panels = {"c1": c1, "c2": c2, "c3": c3}
+    checked = 0
+    for fi, flags in enumerate(FUZZ_FLAG_SETS):
+        name = ("c2", "c3", "c1")[(seed + fi) % 3]
+        pan, (pf, sf) = panels[name]
+        flags = dict(flags)
+        gen = {k: flags.pop(k) for k in ("error_rate", "n_frac") if k in flags}   # generator-only knobs
+        S_ = flags.get("search_len", 80)
+        rs = synth.make_reads(pan, 400, 7000 + 131 * seed + fi, search_len=S_, windows_only=False, **gen)
+        reads = reads_from_set(rs, range(400), S_)
+        both = Both(pf, sf, **flags)
+        both.assert_hits_equal(reads[:40], f"fuzz {name} seed {seed} {flags}")
+        both.assert_ops_equal(reads, f"fuzz {name} seed {seed} {flags}")
+        checked += len(reads)
+    assert checked == 400 * len(FUZZ_FLAG_SETS)
+
+
+# ------------------------------------------------------------------ the 8-GPU configs at per-rank shard size, one shard after another
+def _shards_on_one_gpu(cp, both, pan, n_shards, reads_per_shard, seed0, S_, n_specimens, label, sample, **gen):
+    """What rank r of an 8-GPU run does, for r = 0..7 in turn on this GPU: its own shard (seed0 + r, the bench's
+    shard_seed rule), properties + an oracle sample per shard; the counts vectors summed like the all-reduce would."""
+    from specimux_amd import _lib, synth
+    from specimux_amd.distributed import shard_seed
+    total = np.zeros(cp.counts_len, dtype=np.uint64)
+    for r in range(n_shards):
+        rs = synth.make_reads(pan, reads_per_shard, shard_seed(seed0, r), workers=16, search_len=S_, **gen)
+        total += _full_size_properties(cp, both, rs, S_, n_specimens, f"{label} shard {r}", sample=sample)
+        del rs
+    assert total[_lib.CNT_TOTAL] == n_shards * reads_per_shard and total[_lib.CNT_OVERFLOW] == 0
+    assert total[_lib.CNT_SPECIMEN0:].sum() == total[_lib.CNT_OPS_FULL]
+    return total
+
+
+def test_config4_shards_768_specimens_50M(lib, c2):
+    """configs[3]: the 768-specimen panel, 50 M reads over 8 GPUs = 6.25 M reads per rank.  The eight shards run one after
+    another on this one GPU (seed 4004 + rank); per shard: counter consistency, idempotence and 1 500 seeded reads against
+    the oracle record by record; the summed counts vector is what the RCCL reduce would deliver."""
+    from specimux_amd import _lib
+    from specimux_amd.demultiplex import compiled_panel
+    pan, (pf, sf) = c2
+    both = Both(pf, sf)
+    cp = compiled_panel(both.specimens, both.parameters, both.args, both.prefilter)
+    total = _shards_on_one_gpu(cp, both, pan, 8, 6_250_000, 4004, 80, 768, "c4", 1500)
+    assert 0.5 < total[_lib.CNT_MATCHED] / 50_000_000 < 0.9
+    assert total[_lib.CNT_SPECIMEN0:].min() > 0.5 * total[_lib.CNT_SPECIMEN0:].mean()   # every specimen of the grid demultiplexes
+
+
+def test_config5_shards_stress_10M(lib, c3):
+    """configs[4]: 3072 specimens, degenerate primers, -l 160, 15 % error reads of 2-5 kb, 10 M reads over 8 GPUs = 1.25 M
+    per rank, shard after shard on this GPU (seed 5005 + rank); 600 oracle reads per shard."""
+    from specimux_amd import _lib
+    from specimux_amd.demultiplex import compiled_panel
+    pan, (pf, sf) = c3
+    both = Both(pf, sf, search_len=160)
+    cp = compiled_panel(both.specimens, both.parameters, both.args, both.prefilter)
+    total = _shards_on_one_gpu(cp, both, pan, 8, 1_250_000, 5005, 160, 3072, "c5", 600, error_rate=0.15, insert_mean=3500,
+                               insert_sd=800, insert_min=2000, insert_max=5000, n_frac=0.02)
+    assert total[_lib.CNT_MATCHED] / 10_000_000 > 0.2
+
+
+# ------------------------------------------------------------------ long-lived panels, multi-rank record path, -n under sharding
+def test_panel_reused_by_many_pipeline_runs(lib, c2, tmp_path):
+    """One CompiledPanel through the streaming pipeline eight times: every run creates three lanes (own streams) and
+    destroys them; the panel's per-stream slots (16) must be given back, and every run must write the same tree."""
+    from specimux_amd import synth
+    from specimux_amd.demultiplex import compiled_panel
+    from specimux_amd.pipeline import run_streaming
+    pan, (pf, sf) = c2
+    both = Both(pf, sf)
+    cp = compiled_panel(both.specimens, both.parameters, both.args, both.prefilter)
+    rs = synth.make_reads(pan, 2000, 616, windows_only=False)
+    fq = tmp_path / "reads.fastq"
+    rs.write_fastq(str(fq))
+    first = None
+    for i in range(8):
+        out = tmp_path / f"out{i}"
+        total, matched, counts, _fq = run_streaming(str(fq), cp, str(out), "")
+        got = (total, matched, counts.tolist(), read_expected_tree(str(out)))
+        assert total == 2000
+        if first is None:
+            first = got
+        assert got == first
+
+
+def _tree_text(root, sort_records=False):
+    import os
+    out = {}
+    for dirpath, _d, files in os.walk(root):
+        for fn in files:
+            if fn == "log.txt" or "trace" in os.path.relpath(dirpath, root).split(os.sep):
+                continue
+            text = open(os.path.join(dirpath, fn)).read()
+            out[os.path.relpath(os.path.join(dirpath, fn), root)] = sorted(text.split("@read")) if sort_records else text
+    return out
+
+
+def _two_rank_cli(pf, sf, fq, out, extra_args, tmp_path):
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, SMX_DIST_BACKEND="gloo", PYTHONPATH=REPO)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                    "127.0.0.1", "--master-port", str(29900 + os.getpid() % 300), "-m", "specimux_amd.cli", pf, sf, str(fq),
+                    "-F", "-O", str(out)] + extra_args, check=True, env=env, timeout=600, cwd=REPO)
+
+
+def test_cli_two_rank_trace_run_is_rank0_only(lib, c2, tmp_path):
+    """`-F -d 1` under a two-process launch: the record path is one process's job -- rank 0 runs it, rank 1 leaves -- so the
+    tree equals the single-process tree (no duplicated records) and there is one trace file per batch, not two."""
+    import glob
+    from specimux_amd import cli, synth
+    pan, (pf, sf) = c2
+    rs = synth.make_reads(pan, 600, 517, windows_only=False)
+    fq = tmp_path / "reads.fastq"
+    rs.write_fastq(str(fq))
+    one, two = tmp_path / "one", tmp_path / "two"
+    cli.main(["specimux", pf, sf, str(fq), "-F", "-O", str(one), "-d", "1"])
+    _two_rank_cli(pf, sf, fq, two, ["-d", "1"], tmp_path)
+    assert _tree_text(one) == _tree_text(two)
+    assert len(glob.glob(str(two / "trace" / "*.tsv"))) == len(glob.glob(str(one / "trace" / "*.tsv"))) == 1
+
+
+def test_cli_two_rank_record_window(lib, c2, tmp_path):
+    """`-n start,num` under a two-process launch (the reference's -F path takes it too, cli.py:54-68): every rank reads the
+    file, applies the window and keeps every second batch; same records, file by file, as the single-process run."""
+    from specimux_amd import cli, synth
+    pan, (pf, sf) = c2
+    rs = synth.make_reads(pan, 3000, 518, windows_only=False)
+    fq = tmp_path / "reads.fastq"
+    rs.write_fastq(str(fq))
+    one, two = tmp_path / "one", tmp_path / "two"
+    cli.main(["specimux", pf, sf, str(fq), "-F", "-O", str(one), "-n", "101,2000"])
+    _two_rank_cli(pf, sf, fq, two, ["-n", "101,2000"], tmp_path)
+    a, b = _tree_text(one, True), _tree_text(two, True)
+    assert a == b and sum(len(v) - 1 for k, v in a.items() if k.startswith(("full/ITS/ITS1F", "partial", "unknown"))) >= 2000
+    assert "Processed 2,000 sequences" in (two / "log.txt").read_text()

@@ -140,19 +140,19 @@ def cpu_baseline(pf, sf, rs, e2e_dir, budget_reads_per_core=32000, file_reads_pe
 
 
 # ------------------------------------------------------------------ wider scopes (N = 1, after the timed region)
-def pcie_inclusive(cp, windows, lens, rounds=6):
+def pcie_inclusive(cp, rs, rounds=6):
     """Host windows in, records out: three pinned lanes in flight (H2D of one batch overlaps the kernels of the previous
-    and the D2H of the one before).  The packer's memcpy into the staging is not part of it (staging filled once)."""
+    and the D2H of the one before).  The windows cross the link as 4-bit codes (smx_lane_submit_packed: what the streaming
+    pipeline ships) and are unpacked on the device; `ascii_windows` = the same with 8-bit windows.  The packer's pass over
+    the bases is not part of it (staging filled once)."""
     from specimux_amd.native_io import Lane
-    n = len(lens)
+    n = len(rs.lens)
     lanes = [Lane(cp, n) for _ in range(3)]
     counts = np.zeros(cp.counts_len, dtype=np.uint64)
-    try:
-        for ln in lanes:
-            ln.windows[:n] = windows
-            ln.lens[:n] = lens
+
+    def run(packed):
         for ln in lanes:               # warm
-            ln.submit(n)
+            (ln.submit_packed if packed else ln.submit)(n)
         for ln in lanes:
             ln.wait(counts)
         t0 = time.perf_counter()
@@ -161,19 +161,31 @@ def pcie_inclusive(cp, windows, lens, rounds=6):
             ln = lanes[i % 3]
             if len(inflight) == 3:
                 inflight.pop(0).wait(counts)
-            ln.submit(n)
+            (ln.submit_packed if packed else ln.submit)(n)
             inflight.append(ln)
         for ln in inflight:
             ln.wait(counts)
         dt = time.perf_counter() - t0
+        h2d = n * ((lanes[0].packed_stride if packed else cp.window_stride) + 4)
+        return {"value": rounds * n / dt, "unit": "reads/s", "ms_per_batch": dt / rounds * 1e3, "lanes": 3,
+                "h2d_bytes_per_batch": h2d, "d2h_bytes_per_batch": n * 32, "h2d_gbps": rounds * h2d / dt / 1e9}
+    try:
+        windows = rs.windows(cp.window_stride)
+        for ln in lanes:
+            ln.windows[:n] = windows
+            ln.lens[:n] = rs.lens
+        asc = run(False)
+        pk = rs.packed_windows(lanes[0].packed_stride)
+        for ln in lanes:
+            ln.packed[:n] = pk
+        out = run(True)
     finally:
         for ln in lanes:
             ln.close()
-    h2d = n * (cp.window_stride + 4)
-    d2h = n * 32
-    return {"value": rounds * n / dt, "unit": "reads/s", "ms_per_batch": dt / rounds * 1e3, "lanes": 3,
-            "h2d_bytes_per_batch": h2d, "d2h_bytes_per_batch": d2h, "h2d_gbps": rounds * h2d / dt / 1e9,
-            "note": "pinned staging -> hipMemcpyAsync H2D -> kernels -> D2H of the 32-byte records, own stream per lane"}
+    out["ascii_windows"] = asc
+    out["note"] = ("pinned staging -> hipMemcpyAsync H2D of 4-bit windows -> unpack kernel -> prescan + demux kernels -> D2H of the "
+                   "32-byte records, own stream per lane")
+    return out
 
 
 def tmpfs_write_ceiling(directory, nbytes, threads):
@@ -557,7 +569,7 @@ def main():
         del db
         torch.cuda.empty_cache()
         out["other_configs"] = {c: side_config(lib, c, dev, stream, tmp) for c in ("c3", "c5")}
-        out["pcie_inclusive"] = pcie_inclusive(cp, rs.windows(cp.window_stride), rs.lens)
+        out["pcie_inclusive"] = pcie_inclusive(cp, rs)
         out["end_to_end"] = end_to_end(pan, pf, sf, a.e2e_reads, e2e_dir)
     if cpu:
         out["gpu_over_cpu"] = out["value"] / cpu["value"]   # kernel-resident rate over the oracle's in-memory rate, same reads

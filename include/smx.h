@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SMX_ABI_VERSION 2
+#define SMX_ABI_VERSION 3
 
 typedef enum {
     SMX_OK = 0,
@@ -169,6 +169,21 @@ int smx_pack_windows(const uint8_t *bases, const uint64_t *offsets, uint32_t n_r
                      uint8_t *windows, int32_t *lens);
 
 /*
+ * The same two windows as 4-bit text codes (the transport format of the lanes: half the bytes across PCIe).  Code of a
+ * base = its index in "ACGTNRYKMSWBDHV", 15 for anything else (such characters match no pattern character in either
+ * format); per read: ceil(search_len / 2) bytes of head window, the same of tail window, base j in byte j / 2 (low nibble
+ * first), unused nibbles 15; stride = smx_packed_stride(panel) = round16(2 * ceil(search_len / 2)).
+ * *n_ascii_only (optional) counts the reads with a 'U' inside a window: the one letter the 4-bit alphabet cannot carry
+ * faithfully (Bio.Seq complements U to A); a batch with any must be sent as ASCII windows.
+ * smx_unpack_windows_device turns packed windows resident in device memory into the ASCII layout smx_batch_run_device takes.
+ */
+size_t smx_packed_stride(const smx_panel *panel);
+int smx_pack_windows4(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int32_t search_len,
+                      uint8_t *packed, int32_t *lens, uint32_t *n_ascii_only);
+int smx_unpack_windows_device(const smx_panel *panel, void *stream, const uint8_t *d_packed, uint32_t n_reads,
+                              uint8_t *d_windows);
+
+/*
  * Run the hot path on windows already resident in device memory.  All pointers are DEVICE pointers;
  * `stream` is a hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing.
  *   d_ops          n_reads records
@@ -213,6 +228,7 @@ int smx_batch_run(const smx_panel *panel, const uint8_t *windows, const int32_t 
  *   smx_lane_create    max_reads = capacity of one batch
  *   smx_lane_windows / smx_lane_lens   pinned staging the packer fills (smx_pack_windows_batch writes there directly)
  *   smx_lane_submit    enqueue H2D copy, prescan + demux kernels, D2H copy on the lane's stream; returns at once
+ *   smx_lane_submit_packed   the same for a staging filled with 4-bit windows (84 instead of 164 bytes per read at -l 80)
  *   smx_lane_wait      block until the lane's batch is done; *ops / *extra point into the lane's pinned result buffers
  *                      (valid until the next submit on this lane); counts (host, smx_counts_len() uint64) is accumulated
  *                      into.  SMX_ERR_OVERFLOW as for smx_batch_run (the extra buffer of a lane holds max_reads records).
@@ -223,6 +239,8 @@ void smx_lane_destroy(smx_lane *lane);
 uint8_t *smx_lane_windows(smx_lane *lane);
 int32_t *smx_lane_lens(smx_lane *lane);
 int smx_lane_submit(smx_lane *lane, uint32_t n_reads);
+/* the staging behind smx_lane_windows holds 4-bit windows (smx_pack_windows4_batch): H2D of half the bytes + unpack kernel */
+int smx_lane_submit_packed(smx_lane *lane, uint32_t n_reads);
 int smx_lane_wait(smx_lane *lane, const smx_op **ops, const smx_op **extra, uint32_t *n_extra, uint64_t *counts);
 
 /*
@@ -291,6 +309,7 @@ uint32_t smx_batch_size(const smx_batch *batch);
 int smx_batch_record(const smx_batch *batch, uint32_t i, const char **id, uint32_t *id_len, const char **seq,
                      const char **qual, uint32_t *seq_len);
 int smx_pack_windows_batch(const smx_batch *batch, int32_t search_len, uint8_t *windows, int32_t *lens);
+int smx_pack_windows4_batch(const smx_batch *batch, int32_t search_len, uint8_t *packed, int32_t *lens, uint32_t *n_ascii_only);
 
 /* index -> name tables for the record headers and paths: concatenated strings with n+1 offsets each */
 typedef struct smx_names {

@@ -97,6 +97,10 @@ size_t blob_add(std::vector<unsigned char> &blob, const std::vector<T> &v) {
 
 #define SMX_MAX_STREAMS 16   // distinct streams one panel may be launched on
 
+extern "C" size_t smx_packed_stride_for(int32_t S);   // smx_io.cpp
+extern "C" int smx_launch_unpack_windows(void *stream, const uint8_t *d_packed, uint8_t *d_windows, uint32_t n_reads, int S,
+                                         int pstride, int wstride, int n_cu);   // smx_pack.hip
+
 struct DevBuf {   // grow-only device buffer of the host-buffer convenience path
     void *p = nullptr;
     size_t cap = 0;
@@ -456,6 +460,7 @@ void smx_panel_destroy(smx_panel *P) {
 
 size_t smx_counts_len(const smx_panel *P) { return P ? (size_t)SMX_CNT_SPECIMEN0 + P->hp.NS : 0; }
 size_t smx_window_stride(const smx_panel *P) { return P ? (size_t)P->hp.wstride : 0; }
+size_t smx_packed_stride(const smx_panel *P) { return P ? smx_packed_stride_for(P->hp.S) : 0; }
 size_t smx_hits_per_read(const smx_panel *P) { return P ? (size_t)2 * P->hp.NP : 0; }
 size_t smx_bdist_per_read(const smx_panel *P) { return P ? (size_t)2 * P->hp.NP * P->hp.maxB : 0; }
 
@@ -681,6 +686,17 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     return SMX_OK;
 }
 
+int smx_unpack_windows_device(const smx_panel *Pc, void *stream, const uint8_t *d_packed, uint32_t n_reads, uint8_t *d_windows) {
+    smx_panel *P = const_cast<smx_panel *>(Pc);
+    if (!P || !d_packed || !d_windows) return fail(SMX_ERR_ARG, "null argument");
+    if (((uintptr_t)d_packed & 3) != 0 || ((uintptr_t)d_windows & 15) != 0) return fail(SMX_ERR_ARG, "window buffers must be 16-byte aligned");
+    int rc = ensure_device(P);
+    if (rc) return rc;
+    int e = smx_launch_unpack_windows(stream, d_packed, d_windows, n_reads, P->hp.S, (int)smx_packed_stride_for(P->hp.S), P->hp.wstride, P->n_cu);
+    if (e != 0) return fail(SMX_ERR_DEVICE, "unpack kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return SMX_OK;
+}
+
 int smx_debug_kernel_times(smx_panel *P, int enable, float ms[3]) {
     if (!P) return fail(SMX_ERR_ARG, "null argument");
     if (ms) {
@@ -881,6 +897,7 @@ struct smx_lane {
     uint64_t *h_counts = nullptr;   // counts vector followed by one word holding n_extra
     // device
     uint8_t *d_windows = nullptr;
+    uint8_t *d_packed = nullptr;    // 4-bit windows as they arrive over PCIe (smx_lane_submit_packed)
     int32_t *d_lens = nullptr;
     smx_op *d_ops = nullptr, *d_extra = nullptr;
     uint64_t *d_counts = nullptr;   // same layout as h_counts
@@ -899,6 +916,7 @@ void smx_lane_destroy(smx_lane *L) {
     if (L->h_extra) (void)hipHostFree(L->h_extra);
     if (L->h_counts) (void)hipHostFree(L->h_counts);
     if (L->d_windows) (void)hipFree(L->d_windows);
+    if (L->d_packed) (void)hipFree(L->d_packed);
     if (L->d_lens) (void)hipFree(L->d_lens);
     if (L->d_ops) (void)hipFree(L->d_ops);
     if (L->d_extra) (void)hipFree(L->d_extra);
@@ -924,6 +942,7 @@ int smx_lane_create(const smx_panel *Pc, uint32_t max_reads, smx_lane **out) {
     LANE_TRY(hipHostMalloc((void **)&L->h_extra, ob, hipHostMallocDefault));
     LANE_TRY(hipHostMalloc((void **)&L->h_counts, cb, hipHostMallocDefault));
     LANE_TRY(hipMalloc((void **)&L->d_windows, wb));
+    LANE_TRY(hipMalloc((void **)&L->d_packed, (size_t)max_reads * smx_packed_stride_for(P->hp.S)));
     LANE_TRY(hipMalloc((void **)&L->d_lens, (size_t)max_reads * 4));
     LANE_TRY(hipMalloc((void **)&L->d_ops, ob));
     LANE_TRY(hipMalloc((void **)&L->d_extra, ob));
@@ -936,7 +955,11 @@ int smx_lane_create(const smx_panel *Pc, uint32_t max_reads, smx_lane **out) {
 uint8_t *smx_lane_windows(smx_lane *L) { return L ? L->h_windows : nullptr; }
 int32_t *smx_lane_lens(smx_lane *L) { return L ? L->h_lens : nullptr; }
 
-int smx_lane_submit(smx_lane *L, uint32_t n_reads) {
+static int lane_submit(smx_lane *L, uint32_t n_reads, bool packed);
+int smx_lane_submit(smx_lane *L, uint32_t n_reads) { return lane_submit(L, n_reads, false); }
+int smx_lane_submit_packed(smx_lane *L, uint32_t n_reads) { return lane_submit(L, n_reads, true); }
+
+static int lane_submit(smx_lane *L, uint32_t n_reads, bool packed) {
     if (!L) return fail(SMX_ERR_ARG, "null argument");
     if (L->busy) return fail(SMX_ERR_ARG, "lane already has a batch in flight: smx_lane_wait first");
     HIP_TRY(hipSetDevice(L->P->device));   // lanes are driven from reader / writer threads: device selection is per thread
@@ -946,7 +969,13 @@ int smx_lane_submit(smx_lane *L, uint32_t n_reads) {
     L->n = n_reads;
     HIP_TRY(hipMemsetAsync(L->d_counts, 0, (ncnt + 1) * 8, L->stream));
     if (n_reads) {
-        HIP_TRY(hipMemcpyAsync(L->d_windows, L->h_windows, (size_t)n_reads * P->hp.wstride, hipMemcpyHostToDevice, L->stream));
+        if (packed) {   // the staging holds 4-bit windows: half the bytes over the link, unpacked into the ASCII layout on the device
+            const size_t ps = smx_packed_stride_for(P->hp.S);
+            HIP_TRY(hipMemcpyAsync(L->d_packed, L->h_windows, (size_t)n_reads * ps, hipMemcpyHostToDevice, L->stream));
+            int ue = smx_launch_unpack_windows(L->stream, L->d_packed, L->d_windows, n_reads, P->hp.S, (int)ps, P->hp.wstride, P->n_cu);
+            if (ue != 0) return fail(SMX_ERR_DEVICE, "unpack kernel launch failed: %s", hipGetErrorString((hipError_t)ue));
+        } else
+            HIP_TRY(hipMemcpyAsync(L->d_windows, L->h_windows, (size_t)n_reads * P->hp.wstride, hipMemcpyHostToDevice, L->stream));
         HIP_TRY(hipMemcpyAsync(L->d_lens, L->h_lens, (size_t)n_reads * 4, hipMemcpyHostToDevice, L->stream));
         int rc = smx_batch_run_device(P, L->stream, L->d_windows, L->d_lens, n_reads, L->d_ops, L->d_extra, L->cap,
                                       (uint32_t *)(L->d_counts + ncnt), L->d_counts, nullptr, nullptr);

@@ -867,6 +867,88 @@ int smx_pack_windows_batch(const smx_batch *b, int32_t S, uint8_t *windows, int3
     return SMX_OK;
 }
 
+// ---- 4-bit windows (transport format of the lanes; unpacked on the device by smx_pack.hip)
+namespace {
+struct Code4 {
+    uint8_t code[256];
+    Code4() {
+        static const char chars[16] = {'A', 'C', 'G', 'T', 'N', 'R', 'Y', 'K', 'M', 'S', 'W', 'B', 'D', 'H', 'V', 0};   // smx_internal.h kCodeChars
+        memset(code, 15, sizeof(code));
+        for (int c = 0; c < 15; c++) code[(unsigned char)chars[c]] = (uint8_t)c;
+    }
+};
+const uint8_t *code4_lut() { static Code4 t; return t.code; }
+
+// one read: head / tail windows as nibbles (base j at byte j / 2, low nibble first), padded with code 15.
+// Returns 1 if a window holds 'U': the one letter whose complement is inside the alphabet while the letter itself is not
+// (Bio.Seq: U -> A), so the ASCII windows carry more than its code says -- such a batch travels as ASCII.
+inline int pack4_read(const uint8_t *seq, int L, int S, uint8_t *out, size_t pstride) {
+    const uint8_t *lut = code4_lut();
+    const int Sp = L < S ? L : S, hb = (S + 1) >> 1;
+    int special = 0;
+    for (int end = 0; end < 2; end++) {
+        const uint8_t *src = end ? seq + (L - Sp) : seq;
+        uint8_t *dst = out + (end ? hb : 0);
+        int j = 0;
+        for (; j + 1 < Sp; j += 2) {
+            const uint8_t a = src[j], b = src[j + 1];
+            special |= (a == 'U') | (b == 'U');
+            dst[j >> 1] = (uint8_t)(lut[a] | (lut[b] << 4));
+        }
+        if (j < Sp) { special |= src[j] == 'U'; dst[j >> 1] = (uint8_t)(lut[src[j]] | 0xF0u); j += 2; }
+        for (; j < 2 * hb; j += 2) dst[j >> 1] = 0xFF;
+    }
+    for (size_t k = (size_t)2 * hb; k < pstride; k++) out[k] = 0xFF;
+    return special;
+}
+}  // namespace
+
+size_t smx_packed_stride_for(int32_t S) { return ((size_t)(2 * ((S + 1) >> 1)) + 15) & ~(size_t)15; }
+
+int smx_pack_windows4(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, int32_t S, uint8_t *packed, int32_t *lens,
+                      uint32_t *n_ascii_only) {
+    if (!bases || !offsets || !packed || !lens || S < 1) return smx_set_error(SMX_ERR_ARG, "null argument");
+    const size_t ps = smx_packed_stride_for(S);
+    uint32_t special = 0;
+    for (uint32_t i = 0; i < n_reads; i++) {
+        const uint64_t a = offsets[i], b = offsets[i + 1];
+        if (b < a || b - a > 0x7FFFFFFFull) return smx_set_error(SMX_ERR_ARG, "read %u: bad offsets", i);
+        special += (uint32_t)pack4_read(bases + a, (int)(b - a), S, packed + (size_t)i * ps, ps);
+        lens[i] = (int32_t)(b - a);
+    }
+    if (n_ascii_only) *n_ascii_only = special;
+    return SMX_OK;
+}
+
+int smx_pack_windows4_batch(const smx_batch *b, int32_t S, uint8_t *packed, int32_t *lens, uint32_t *n_ascii_only) {
+    if (!b || !packed || !lens || S < 1) return smx_set_error(SMX_ERR_ARG, "null argument");
+    const size_t ps = smx_packed_stride_for(S);
+    const int T = (int)std::min<size_t>((size_t)io_threads(), std::max<size_t>(b->segs.size(), 1));
+    std::atomic<size_t> next(0);
+    std::atomic<uint32_t> special(0);
+    auto work = [&] {
+        uint32_t sp = 0;
+        for (size_t k = next.fetch_add(1); k < b->segs.size(); k = next.fetch_add(1)) {
+            const Segment &sg = b->segs[k];
+            for (size_t j = 0; j < sg.recs.size(); j++) {
+                const Rec &r = sg.recs[j];
+                const size_t i = (size_t)b->first[k] + j;
+                sp += (uint32_t)pack4_read((const uint8_t *)sg.base + r.seq_off, (int)r.seq_len, S, packed + i * ps, ps);
+                lens[i] = (int32_t)r.seq_len;
+            }
+        }
+        special.fetch_add(sp);
+    };
+    if (T <= 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(work);
+        for (auto &x : th) x.join();
+    }
+    if (n_ascii_only) *n_ascii_only = special.load();
+    return SMX_OK;
+}
+
 int smx_writer_open(const char *output_dir, const char *prefix, int is_fastq, const smx_names *nm, smx_writer **out) {
     if (!output_dir || !nm || !out) return smx_set_error(SMX_ERR_ARG, "null argument");
     smx_writer *w = new smx_writer();

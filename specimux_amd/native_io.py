@@ -41,6 +41,13 @@ class Batch:
         """Cut the end windows straight into caller-owned buffers (a Lane's pinned staging): no allocation, no copy."""
         _lib.check(self._lib.smx_pack_windows_batch(self.handle, search_len, _lib.ptr(windows), _lib.ptr(lens)))
 
+    def pack_windows4_into(self, search_len, packed, lens):
+        """Cut the end windows as 4-bit codes (include/smx.h smx_pack_windows4_batch) into caller-owned buffers.  Returns
+        the number of reads that cannot travel in this format (a 'U' inside a window): 0 in practice."""
+        n_ascii = C.c_uint32()
+        _lib.check(self._lib.smx_pack_windows4_batch(self.handle, search_len, _lib.ptr(packed), _lib.ptr(lens), C.byref(n_ascii)))
+        return int(n_ascii.value)
+
     def close(self):
         if self.handle:
             self._lib.smx_batch_free(self.handle)
@@ -68,11 +75,19 @@ class Lane:
         lp = C.cast(self._lib.smx_lane_lens(self.handle), C.POINTER(C.c_int32))
         self.windows = np.ctypeslib.as_array(wp, shape=(self.max_reads, panel.window_stride))
         self.lens = np.ctypeslib.as_array(lp, shape=(self.max_reads,))
+        # the same staging seen as 4-bit windows (submit_packed): half the bytes per read
+        self.packed_stride = int(self._lib.smx_packed_stride(panel.handle))
+        self.packed = self.windows.reshape(-1)[:self.max_reads * self.packed_stride].reshape(self.max_reads, self.packed_stride)
         self.n = 0
 
     def submit(self, n):
         self.n = int(n)
         _lib.check(self._lib.smx_lane_submit(self.handle, self.n))
+
+    def submit_packed(self, n):
+        """The staging holds 4-bit windows (Batch.pack_windows4_into(..., lane.packed, lane.lens))."""
+        self.n = int(n)
+        _lib.check(self._lib.smx_lane_submit_packed(self.handle, self.n))
 
     def wait(self, counts):
         """-> (ops, extra) numpy views; `counts` (uint64, panel.counts_len) is accumulated into."""

@@ -43,6 +43,7 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
     for ln in lanes:
         free_lanes.put(ln)
     errors = []
+    ascii_lanes = bool(os.environ.get("SMX_LANES_ASCII"))   # A/B and test hook: ship 8-bit windows
     timing = {"read": 0.0, "pack": 0.0, "submit": 0.0, "gpu_wait": 0.0, "write": 0.0, "close": 0.0}
     n_delivered = [0]
     t_start = time.perf_counter()
@@ -78,9 +79,15 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                     b.close()
                     break
                 t2 = time.perf_counter()
-                b.pack_windows_into(panel.search_len, lane.windows, lane.lens)
-                t3 = time.perf_counter()
-                lane.submit(len(b))
+                # 4-bit windows across PCIe (84 instead of 164 bytes per read at -l 80), unpacked on the device; a batch
+                # with a 'U' inside a window (the one letter the 4-bit alphabet cannot carry) travels as ASCII
+                if ascii_lanes or b.pack_windows4_into(panel.search_len, lane.packed, lane.lens) > 0:
+                    b.pack_windows_into(panel.search_len, lane.windows, lane.lens)
+                    t3 = time.perf_counter()
+                    lane.submit(len(b))
+                else:
+                    t3 = time.perf_counter()
+                    lane.submit_packed(len(b))
                 timing["read"] += t1 - t0
                 timing["pack"] += t3 - t2
                 timing["submit"] += time.perf_counter() - t3
@@ -130,7 +137,8 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                     raise
                 # more extra records than a lane holds (pathological tie storms): this batch again, synchronously,
                 # with a buffer of the size the kernel asked for
-                ops, extra, _ = panel.run(lane.windows[:len(b)].copy(), lane.lens[:len(b)].copy(), counts=counts)
+                windows, lens = b.pack_windows(panel.search_len, panel.window_stride)
+                ops, extra, _ = panel.run(windows, lens, counts=counts)
             timing["gpu_wait"] += time.perf_counter() - t0
             q_out.put((b, lane, ops, extra))
             if on_batch:

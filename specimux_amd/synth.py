@@ -175,6 +175,19 @@ class ReadSet:
         w[:, S:2 * S] = self.tail
         return w
 
+    def packed_windows(self, pstride):
+        """The same windows as 4-bit codes (include/smx.h smx_pack_windows4): [n, pstride] uint8."""
+        n, S = self.head.shape
+        lut = np.full(256, 15, dtype=np.uint8)
+        lut[np.frombuffer(b"ACGTNRYKMSWBDHV", dtype=np.uint8)] = np.arange(15, dtype=np.uint8)
+        hb = (S + 1) // 2
+        out = np.full((n, pstride), 0xFF, dtype=np.uint8)
+        for e, arr in enumerate((self.head, self.tail)):
+            codes = np.full((n, 2 * hb), 15, dtype=np.uint8)
+            codes[:, :S] = lut[arr]
+            out[:, e * hb:(e + 1) * hb] = codes[:, 0::2] | (codes[:, 1::2] << 4)
+        return out
+
     def write_fastq(self, path):
         with open(path, "w") as fh:
             for i, (s, q) in enumerate(zip(self.reads, self.quals)):

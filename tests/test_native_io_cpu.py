@@ -148,6 +148,56 @@ def test_pack_windows_batch_equals_pack_windows():
     assert np.array_equal(w1, w2) and np.array_equal(l1, l2)
 
 
+def _pack4_reference(seqs, S, pstride):
+    """4-bit windows restated in numpy (include/smx.h smx_pack_windows4): base j of a window in byte j / 2, low nibble
+    first, code = index in ACGTNRYKMSWBDHV or 15; -> (packed, number of reads with a 'U' inside a window)."""
+    lut = np.full(256, 15, dtype=np.uint8)
+    lut[np.frombuffer(b"ACGTNRYKMSWBDHV", dtype=np.uint8)] = np.arange(15, dtype=np.uint8)
+    hb = (S + 1) // 2
+    out = np.full((len(seqs), pstride), 0xFF, dtype=np.uint8)
+    special = 0
+    for i, s in enumerate(seqs):
+        a = np.frombuffer(s.encode("latin-1"), dtype=np.uint8)
+        Sp = min(len(a), S)
+        for e, w in enumerate((a[:Sp], a[len(a) - Sp:])):
+            codes = np.full(2 * hb, 15, dtype=np.uint8)
+            codes[:Sp] = lut[w]
+            out[i, e * hb:(e + 1) * hb] = codes[0::2] | (codes[1::2] << 4)
+        special += int((a[:Sp] == 85).any() or (a[len(a) - Sp:] == 85).any())
+    return out, special
+
+
+@pytest.mark.parametrize("search_len", [80, 81, 7, 1, 160])
+def test_pack_windows4_equals_numpy_restatement(tmp_path, search_len):
+    """The 4-bit packer (both entry points: parsed batch and flat arrays) against a numpy restatement: every IUPAC letter,
+    lower case, other characters, 'U', reads shorter than the window, empty-ish reads."""
+    import ctypes as C
+    from specimux_amd import _lib
+    from specimux_amd.native_io import Reader
+    lib = _lib.load()
+    rng = np.random.default_rng(search_len)
+    alphabet = "ACGTACGTACGTACGTNRYKMSWBDHVacgtnXU?-"
+    lens = rng.integers(1, 3 * search_len + 6, 400)
+    seqs = ["".join(alphabet[k] for k in rng.integers(0, len(alphabet), L)) for L in lens]
+    pstride = (2 * ((search_len + 1) // 2) + 15) & ~15
+    exp, n_u = _pack4_reference(seqs, search_len, pstride)
+    assert n_u > 0
+    # flat arrays
+    bases = np.frombuffer("".join(seqs).encode("latin-1"), dtype=np.uint8)
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    packed, ol, nsp = np.zeros((len(seqs), pstride), dtype=np.uint8), np.zeros(len(seqs), dtype=np.int32), C.c_uint32()
+    _lib.check(lib.smx_pack_windows4(_lib.ptr(bases), _lib.ptr(off), len(seqs), search_len, _lib.ptr(packed), _lib.ptr(ol), C.byref(nsp)))
+    assert np.array_equal(packed, exp) and np.array_equal(ol, lens) and nsp.value == n_u
+    # parsed batch (threaded)
+    fq = tmp_path / "r.fastq"
+    fq.write_text("".join(f"@r{i}\n{s}\n+\n{'I' * len(s)}\n" for i, s in enumerate(seqs)))
+    b = Reader(str(fq)).next_batch(1000)
+    packed2, ol2 = np.zeros_like(packed), np.zeros_like(ol)
+    assert b.pack_windows4_into(search_len, packed2, ol2) == n_u
+    assert np.array_equal(packed2, exp) and np.array_equal(ol2, lens)
+
+
 def _ops_from_oracle(cp, oracle_ops, n_reads, id_to_index):
     """Oracle write operations -> (ops[n_reads], extra[]) smx_op arrays."""
     from specimux_amd import _lib

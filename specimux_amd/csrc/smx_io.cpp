@@ -17,6 +17,7 @@
 //     worker only builds record descriptors that point into the block.  The first irregular record (wrapped
 //     lines, blank lines) switches the reader permanently to the general engine at that block's offset.
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -77,6 +78,13 @@ struct Blob {
     void resize(size_t m) { n = m; }   // shrink only
 };
 
+// read-only mapping of the whole input file (fast engine): batches point straight into the page cache
+struct Mapping {
+    const char *p = nullptr;
+    size_t n = 0;
+    ~Mapping() { if (p) munmap((void *)p, n); }
+};
+
 struct Rec {
     uint64_t id_off, seq_off, qual_off;   // into the segment's base; qual_off == UINT64_MAX for FASTA
     uint32_t id_len, seq_len;
@@ -94,7 +102,7 @@ struct Segment {
 struct smx_batch {
     std::vector<Segment> segs;
     std::vector<uint32_t> first;          // first[i] = global index of segs[i].recs[0]; first.back() = total
-    std::shared_ptr<Blob> block;   // fast engine: the file block the segments point into
+    std::shared_ptr<void> block;   // fast engine: what the segments point into (a file mapping, or an inflated / copied block)
     uint32_t n = 0;
 
     void clear() { segs.clear(); first.clear(); block.reset(); n = 0; }
@@ -123,6 +131,7 @@ struct smx_reader {
     int fd = -1;
     uint64_t fsize = 0, fpos = 0;
     bool fast = false;
+    std::shared_ptr<Mapping> map;   // the file, mapped read-only (nullptr: blocks are copied with pread)
     // ---- fast engine on gzip input: inflate a block, then parse it in parallel
     bool gzfast = false, gz_eof = false;
     std::vector<char> carry;
@@ -331,9 +340,9 @@ bool parse_strict(const char *base, const char *p, const char *stop, const char 
 // offset of the first unconsumed byte; 0 = irregular input (the general engine must take over from the block start);
 // 2 = no complete record in the block (caller retries with a bigger block); 3 = nothing but white space up to the
 // end of the input.
-int parse_block(const std::shared_ptr<Blob> &block, uint64_t len, bool last_block, uint32_t max_reads, smx_batch *b,
+int parse_block(const std::shared_ptr<void> &block, const char *base, uint64_t len, bool last_block, uint32_t max_reads, smx_batch *b,
                 uint64_t *next_off_out) {
-    const char *base = block->data(), *end = base + len;
+    const char *end = base + len;
     const int T = io_threads();
     std::vector<const char *> cut(T + 1);
     cut[0] = base;
@@ -406,6 +415,17 @@ int next_fast(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batch *
     for (;;) {
         uint64_t len = std::min<uint64_t>(want, r->fsize - r->fpos);
         bool last_block = r->fpos + len >= r->fsize;
+        if (r->map) {
+            // zero-copy: the block IS the page cache (mapped read-only); the parser threads fault their own parts in.  What
+            // the copying path below spends on moving every input byte once more is most of a reader's time on cached files.
+            uint64_t next_off = 0;
+            int rc = parse_block(r->map, r->map->p + r->fpos, len, last_block, max_reads, b, &next_off);
+            if (rc == 0) return 0;
+            if (rc == 3) { r->fpos = r->fsize; return 1; }
+            if (rc == 2) { want *= 2; continue; }
+            r->fpos += next_off;
+            return 1;
+        }
         auto block = std::make_shared<Blob>(len);
         if (!block->data()) { smx_set_error(SMX_ERR_ARG, "out of memory reading %s", r->path.c_str()); return -1; }
         // the block is read by all I/O threads at once (page-cache copies scale with threads)
@@ -437,7 +457,7 @@ int next_fast(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batch *
         }
         if (got < len) { len = got; last_block = true; block->resize(len); }
         uint64_t next_off = 0;
-        int rc = parse_block(block, len, last_block, max_reads, b, &next_off);
+        int rc = parse_block(block, block->data(), len, last_block, max_reads, b, &next_off);
         if (rc == 0) return 0;
         if (rc == 3) { r->fpos = r->fsize; return 1; }
         if (rc == 2) { want *= 2; continue; }
@@ -469,7 +489,7 @@ int next_fast_gz(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batc
         }
         block->resize(len);
         uint64_t next_off = 0;
-        int rc = parse_block(block, len, r->gz_eof, max_reads, b, &next_off);
+        int rc = parse_block(block, block->data(), len, r->gz_eof, max_reads, b, &next_off);
         if (rc == 0) return 0;
         if (rc == 3) { r->carry.clear(); r->upos += len; return 1; }
         if (rc == 2) { r->carry.assign(block->data(), block->data() + len); want *= 2; continue; }
@@ -515,6 +535,7 @@ struct smx_writer {
         int rc = 0;
     };
     std::vector<Shard> shards;
+    size_t flush_bytes = 256u << 10;   // a file's pending records are appended once they exceed this (SMX_IO_FLUSH_KB)
 
     static void mkdirs(const std::string &path) {
         for (size_t i = 1; i < path.size(); i++)
@@ -654,8 +675,8 @@ int write_one(smx_writer *w, smx_writer::Shard &sh, uint32_t me, uint32_t T, con
         std::string &d2 = sh.files[f2].pending;
         d2.append(dst, rec0, std::string::npos);
     }
-    if (mine1 && sh.files[f1].pending.size() > (256u << 10)) smx_writer::flush(sh, sh.files[f1]);
-    if (mine2 && sh.files[f2].pending.size() > (256u << 10)) smx_writer::flush(sh, sh.files[f2]);
+    if (mine1 && sh.files[f1].pending.size() > w->flush_bytes) smx_writer::flush(sh, sh.files[f1]);
+    if (mine2 && sh.files[f2].pending.size() > w->flush_bytes) smx_writer::flush(sh, sh.files[f2]);
     return SMX_OK;
 }
 
@@ -709,6 +730,15 @@ int smx_reader_open(const char *path, smx_reader **out, int *is_fastq) {
             r->fsize = (uint64_t)st.st_size;
             r->fpos = 0;
             r->fast = true;
+            if (r->fsize > 0 && !getenv("SMX_IO_NO_MMAP")) {   // (a file truncated while mapped faults: inputs are complete files)
+                void *m = mmap(nullptr, (size_t)r->fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    (void)madvise(m, (size_t)r->fsize, MADV_SEQUENTIAL);
+                    r->map = std::make_shared<Mapping>();
+                    r->map->p = (const char *)m;
+                    r->map->n = (size_t)r->fsize;
+                }
+            }
         } else if (fd >= 0) close(fd);
     }
     if (r->fastq && !r->fast && gzdirect(gz) == 0 && !getenv("SMX_IO_SERIAL")) {
@@ -871,34 +901,36 @@ int smx_pack_windows_batch(const smx_batch *b, int32_t S, uint8_t *windows, int3
 namespace {
 struct Code4 {
     uint8_t code[256];
+    uint8_t pair[65536];   // two consecutive bases (little-endian 16-bit load) -> one packed byte: 64 KB, cache resident
     Code4() {
         static const char chars[16] = {'A', 'C', 'G', 'T', 'N', 'R', 'Y', 'K', 'M', 'S', 'W', 'B', 'D', 'H', 'V', 0};   // smx_internal.h kCodeChars
         memset(code, 15, sizeof(code));
         for (int c = 0; c < 15; c++) code[(unsigned char)chars[c]] = (uint8_t)c;
+        for (int v = 0; v < 65536; v++) pair[v] = (uint8_t)(code[v & 255] | (code[v >> 8] << 4));
     }
 };
-const uint8_t *code4_lut() { static Code4 t; return t.code; }
+const Code4 *code4_tables() { static Code4 t; return &t; }
 
 // one read: head / tail windows as nibbles (base j at byte j / 2, low nibble first), padded with code 15.
 // Returns 1 if a window holds 'U': the one letter whose complement is inside the alphabet while the letter itself is not
 // (Bio.Seq: U -> A), so the ASCII windows carry more than its code says -- such a batch travels as ASCII.
-inline int pack4_read(const uint8_t *seq, int L, int S, uint8_t *out, size_t pstride) {
-    const uint8_t *lut = code4_lut();
+inline int pack4_read(const Code4 &T, const uint8_t *seq, int L, int S, uint8_t *out, size_t pstride) {
     const int Sp = L < S ? L : S, hb = (S + 1) >> 1;
     int special = 0;
     for (int end = 0; end < 2; end++) {
         const uint8_t *src = end ? seq + (L - Sp) : seq;
         uint8_t *dst = out + (end ? hb : 0);
+        special |= Sp > 0 && memchr(src, 'U', (size_t)Sp) != nullptr;
         int j = 0;
         for (; j + 1 < Sp; j += 2) {
-            const uint8_t a = src[j], b = src[j + 1];
-            special |= (a == 'U') | (b == 'U');
-            dst[j >> 1] = (uint8_t)(lut[a] | (lut[b] << 4));
+            uint16_t two;
+            memcpy(&two, src + j, 2);
+            dst[j >> 1] = T.pair[two];
         }
-        if (j < Sp) { special |= src[j] == 'U'; dst[j >> 1] = (uint8_t)(lut[src[j]] | 0xF0u); j += 2; }
-        for (; j < 2 * hb; j += 2) dst[j >> 1] = 0xFF;
+        if (j < Sp) { dst[j >> 1] = (uint8_t)(T.code[src[j]] | 0xF0u); j += 2; }
+        if (j < 2 * hb) memset(dst + (j >> 1), 0xFF, (size_t)(hb - (j >> 1)));
     }
-    for (size_t k = (size_t)2 * hb; k < pstride; k++) out[k] = 0xFF;
+    if ((size_t)2 * hb < pstride) memset(out + 2 * hb, 0xFF, pstride - (size_t)2 * hb);
     return special;
 }
 }  // namespace
@@ -909,11 +941,12 @@ int smx_pack_windows4(const uint8_t *bases, const uint64_t *offsets, uint32_t n_
                       uint32_t *n_ascii_only) {
     if (!bases || !offsets || !packed || !lens || S < 1) return smx_set_error(SMX_ERR_ARG, "null argument");
     const size_t ps = smx_packed_stride_for(S);
+    const Code4 &T4 = *code4_tables();
     uint32_t special = 0;
     for (uint32_t i = 0; i < n_reads; i++) {
         const uint64_t a = offsets[i], b = offsets[i + 1];
         if (b < a || b - a > 0x7FFFFFFFull) return smx_set_error(SMX_ERR_ARG, "read %u: bad offsets", i);
-        special += (uint32_t)pack4_read(bases + a, (int)(b - a), S, packed + (size_t)i * ps, ps);
+        special += (uint32_t)pack4_read(T4, bases + a, (int)(b - a), S, packed + (size_t)i * ps, ps);
         lens[i] = (int32_t)(b - a);
     }
     if (n_ascii_only) *n_ascii_only = special;
@@ -923,6 +956,7 @@ int smx_pack_windows4(const uint8_t *bases, const uint64_t *offsets, uint32_t n_
 int smx_pack_windows4_batch(const smx_batch *b, int32_t S, uint8_t *packed, int32_t *lens, uint32_t *n_ascii_only) {
     if (!b || !packed || !lens || S < 1) return smx_set_error(SMX_ERR_ARG, "null argument");
     const size_t ps = smx_packed_stride_for(S);
+    const Code4 &T4 = *code4_tables();
     const int T = (int)std::min<size_t>((size_t)io_threads(), std::max<size_t>(b->segs.size(), 1));
     std::atomic<size_t> next(0);
     std::atomic<uint32_t> special(0);
@@ -933,7 +967,7 @@ int smx_pack_windows4_batch(const smx_batch *b, int32_t S, uint8_t *packed, int3
             for (size_t j = 0; j < sg.recs.size(); j++) {
                 const Rec &r = sg.recs[j];
                 const size_t i = (size_t)b->first[k] + j;
-                sp += (uint32_t)pack4_read((const uint8_t *)sg.base + r.seq_off, (int)r.seq_len, S, packed + i * ps, ps);
+                sp += (uint32_t)pack4_read(T4, (const uint8_t *)sg.base + r.seq_off, (int)r.seq_len, S, packed + i * ps, ps);
                 lens[i] = (int32_t)r.seq_len;
             }
         }
@@ -963,6 +997,7 @@ int smx_writer_open(const char *output_dir, const char *prefix, int is_fastq, co
     const char *from = "ACGTMRWSYKVHDBXNUacgtmrwsykvhdbxnu", *to = "TGCAKYWSRMBDHVXNAtgcakywsrmbdhvxna";
     for (int i = 0; from[i]; i++) w->comp[(unsigned char)from[i]] = (unsigned char)to[i];
     w->shards.resize((size_t)io_threads());
+    if (const char *e = getenv("SMX_IO_FLUSH_KB")) w->flush_bytes = (size_t)std::max(4, atoi(e)) << 10;
     mkdir(output_dir, 0777);
     *out = w;
     return SMX_OK;
@@ -1012,10 +1047,14 @@ int smx_writer_write(smx_writer *w, const smx_batch *b, const smx_op *ops, uint3
 int smx_writer_close(smx_writer *w) {
     if (!w) return SMX_OK;
     int err = 0;
-    for (auto &sh : w->shards) {
-        for (auto &f : sh.files) smx_writer::flush(sh, f);
-        if (!err) err = sh.first_errno;
+    {   // every shard flushes its own files: the tail of the run is as parallel as the rest
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < w->shards.size(); t++)
+            th.emplace_back([w, t] { for (auto &f : w->shards[t].files) smx_writer::flush(w->shards[t], f); });
+        if (!w->shards.empty()) for (auto &f : w->shards[0].files) smx_writer::flush(w->shards[0], f);
+        for (auto &x : th) x.join();
     }
+    for (auto &sh : w->shards) if (!err) err = sh.first_errno;
     delete w;
     if (err) return smx_set_error(SMX_ERR_ARG, "output write failed: %s", strerror(err));
     return SMX_OK;

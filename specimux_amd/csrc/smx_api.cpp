@@ -150,6 +150,7 @@ struct smx_panel {
     DevBuf pre_planes[SMX_MAX_STREAMS];      // per stream slot: the 2-bit text planes of the batch (read-tile major)
     DevBuf pre_recs[SMX_MAX_STREAMS];
     DevBuf pre_match[SMX_MAX_STREAMS];       // per stream slot: match words [tile][2 * NP][32 groups] (bit = read reaches the threshold)
+    DevBuf pre_codes[SMX_MAX_STREAMS];       // per stream slot: row-major 2-bit codes [read][end][chunk] + one flag byte per read behind them
     // compact mode of the lean kernel (panels with many primers): tiles of Rc reads that keep per-alignment records only
     // for the nitems alignments the match words flag; a tile that needs more goes on the overflow list and is redone by a
     // dense launch (R, lds) right behind the compact one.  nitems == 0: off.
@@ -452,6 +453,7 @@ void smx_panel_destroy(smx_panel *P) {
     for (auto &b : P->ws) b.release();
     for (auto &b : P->pre_recs) b.release();
     for (auto &b : P->pre_match) b.release();
+    for (auto &b : P->pre_codes) b.release();
     for (auto &b : P->ovf) b.release();
     for (auto &b : P->pre_planes) b.release();
     for (auto &e : P->kev) if (e) (void)hipEventDestroy(e);
@@ -625,7 +627,8 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         tc = P->d_tile_counter + 16 * slot;
     }
     // primer prescan in front of the demux kernel (same stream: ordered)
-    const unsigned *d_pre = nullptr;
+    const unsigned *d_pre = nullptr, *d_codes2 = nullptr;
+    const uint8_t *d_naflag = nullptr;
     uint32_t npad = 0;
     if (P->kev_on) { (void)hipEventRecord(P->kev[0], (hipStream_t)stream); P->kev_pre = P->pre_ok; }
     if (P->pre_ok) {
@@ -635,20 +638,27 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         const size_t need_planes = (size_t)(npad / smx::PRE_TILE) * (P->hp.S >> 4) * 8 * 64 * 4 * sizeof(unsigned);
         const size_t need_match = P->nitems > 0 ? (size_t)(npad / smx::PRE_TILE) * 2 * P->hp.NP * smx::PRE_G * sizeof(unsigned) : 0;
         const size_t need_ovf = compact ? ((size_t)n_reads / P->Rc + 2) * sizeof(unsigned) : 0;
-        if (need > pb.cap || need_planes > pp.cap || need_match > pm.cap || need_ovf > ov.cap) {
+        DevBuf &pc = P->pre_codes[slot];
+        const size_t codes_bytes = (size_t)npad * 2 * (P->hp.S >> 4) * sizeof(unsigned);   // 2-bit codes, then the flag bytes
+        const size_t need_codes = codes_bytes + npad;
+        if (need > pb.cap || need_planes > pp.cap || need_match > pm.cap || need_ovf > ov.cap || need_codes > pc.cap) {
             if (pb.p || pp.p) (void)hipStreamSynchronize((hipStream_t)stream);   // earlier launches on this stream still use them
             hipError_t pe = pb.ensure(need);
             if (pe == hipSuccess) pe = pp.ensure(need_planes);
+            if (pe == hipSuccess) pe = pc.ensure(need_codes);
             if (pe == hipSuccess && need_match) pe = pm.ensure(need_match);
             if (pe == hipSuccess && need_ovf) pe = ov.ensure(need_ovf);
             if (pe != hipSuccess) return fail(SMX_ERR_DEVICE, "prescan buffers: %s", hipGetErrorString(pe));
         }
         const uint32_t ptiles = npad / smx::PRE_TILE;
-        const int grid_t = (int)std::min<uint32_t>(ptiles, (uint32_t)(P->n_cu * P->pre_blocks_t));
-        const int grid_d = (int)std::min<uint32_t>(ptiles * (uint32_t)P->hp.NP, (uint32_t)(P->n_cu * P->pre_blocks_d));
+        const int grid_t = (int)std::min<uint32_t>(ptiles * (smx::PRE_G / smx::PRE_SUBG), (uint32_t)(P->n_cu * P->pre_blocks_t));
+        // (DP work items come in groups of 8 tiles x NP primers; grid a multiple of 8: blocks b and b + 8 share an XCD)
+        const int grid_d = (int)std::min<uint32_t>(((ptiles + 7) / 8) * 8 * (uint32_t)P->hp.NP, (uint32_t)(P->n_cu * P->pre_blocks_d));
+        d_codes2 = (const unsigned *)pc.p;
+        d_naflag = (const uint8_t *)pc.p + codes_bytes;
         int pe = smx_launch_prescan(&P->pre, P->pre_mr, P->pre_nx, grid_t, P->pre_lds, grid_d, stream, d_windows, d_lens, n_reads,
                                     P->hp.wstride, (unsigned *)pp.p, (unsigned *)pb.p, P->nitems > 0 ? (unsigned *)pm.p : nullptr,
-                                    P->kev_on ? (void *)P->kev[1] : nullptr);
+                                    P->kev_on ? (void *)P->kev[1] : nullptr, (unsigned *)pc.p, (uint8_t *)pc.p + codes_bytes);
         if (pe != 0) return fail(SMX_ERR_DEVICE, "prescan kernel launch failed: %s", hipGetErrorString((hipError_t)pe));
         d_pre = (const unsigned *)pb.p;
         if (P->kev_on) (void)hipEventRecord(P->kev[2], (hipStream_t)stream);
@@ -659,7 +669,7 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     if (compact) {
         // compact launch over all reads, then the dense launch over the reads of the tiles it put on the overflow list
         // (usually none: its workgroups find an empty list and leave)
-        smx::DemuxAux ax = {(const unsigned *)P->pre_match[slot].p, (unsigned *)P->ovf[slot].p, P->nitems, 0, P->Rc, 1};
+        smx::DemuxAux ax = {(const unsigned *)P->pre_match[slot].p, (unsigned *)P->ovf[slot].p, P->nitems, 0, P->Rc, 1, d_codes2, d_naflag};
         const uint32_t ctiles = (n_reads + P->Rc - 1) / P->Rc;
         const int cgrid = (int)std::min<uint32_t>(ctiles, (uint32_t)(P->n_cu * P->blocks_per_cu_c));
         e = smx_launch_demux(&P->hp, P->use64, P->Rc, cgrid, P->lds_c, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
@@ -673,14 +683,16 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         if (e == 0) {
             // the redo launch usually finds an empty list: one workgroup per CU is enough to start with (its workgroups
             // loop over the list), and an empty 256-workgroup launch costs less than an empty full-residency one
-            smx::DemuxAux rx = {nullptr, (unsigned *)P->ovf[slot].p, 0, 1, P->Rc, 0};
+            smx::DemuxAux rx = {nullptr, (unsigned *)P->ovf[slot].p, 0, 1, P->Rc, 0, d_codes2, d_naflag};
             grid = std::min(grid, P->n_cu);
             e = smx_launch_demux(&P->hp, P->use64, R, grid, lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
                                  extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, 0, d_pre, npad, &rx);
         }
-    } else
+    } else {
+        smx::DemuxAux dx = {nullptr, nullptr, 0, 0, 0, 0, d_codes2, d_naflag};
         e = smx_launch_demux(&P->hp, P->use64, R, grid, lds, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
-                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, use_slots, d_pre, npad, nullptr);
+                             extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, use_slots, d_pre, npad, &dx);
+    }
     if (e != 0) return fail(SMX_ERR_DEVICE, "demux kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     if (P->kev_on) (void)hipEventRecord(P->kev[3], (hipStream_t)stream);
     return SMX_OK;

@@ -58,6 +58,8 @@ struct DemuxAux {
     int redo;                // 1: this launch processes the reads of ovf_list's tiles (Rc reads each) and nothing else
     int Rc;                  // reads per tile of the compact launch
     int chain;               // 1: another launch of this batch follows: the extra-record and overflow counters stay
+    const unsigned *codes2;  // prescan: row-major 2-bit codes per read in DP order (smx_prescan_core.h codes2_word); nullptr: encode from ASCII
+    const uint8_t *naflag;   // prescan: per read, 1 = a window holds something other than upper-case ACGT (ASCII path for that read)
 };
 
 }  // namespace smx
@@ -71,7 +73,7 @@ int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t 
 size_t smx_prescan_lds_bytes(int S);
 int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int grid_t, size_t lds_t, int grid_d, void *stream,
                        const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride, unsigned *d_planes,
-                       unsigned *d_out, unsigned *d_match, void *ev_mid);
+                       unsigned *d_out, unsigned *d_match, void *ev_mid, unsigned *d_codes2, uint8_t *d_naflag);
 int smx_prescan_set_lds_limit(size_t bytes);
 int smx_prescan_occupancy(int S, int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d);
 int smx_prescan_transpose_threads(int S);

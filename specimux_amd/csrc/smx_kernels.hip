@@ -1974,7 +1974,33 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     }
                 }
             };
-            if ((S & 15) == 0) {
+            if ((S & 15) == 0 && aux.codes2 != nullptr) {
+                // behind the prescan: the transpose kernel has already turned every pure-ACGT window into 2-bit codes, row-major
+                // per read and in DP order (end A reverse-complemented): one dword per (read, end, 16-column chunk), the tile's
+                // dwords contiguous.  Four shift/mask/swap steps spell the dword out as 16 code bytes.  Reads the transpose kernel
+                // flagged (a window with anything but upper-case ACGT) and reads shorter than the window take the ASCII path.
+                const int hc = S >> 4, per = 2 * hc;
+                const unsigned *c2 = aux.codes2 + (size_t)r0n * per;
+                const unsigned permagic = (unsigned)((0x100000000ull + (unsigned)per - 1) / (unsigned)per);
+                for (int ci = wid; ci < nrn * per; ci += nw) {
+                    const unsigned z = c2[ci];
+                    const int r = (int)__umulhi((unsigned)ci, permagic), rem = ci - __mul24(r, per);
+                    const int end = rem >= hc ? 1 : 0, c = rem - (end ? hc : 0);
+                    const int L = lens[r0n + r];
+                    const unsigned flagged = aux.naflag[r0n + r];
+                    if (L >= S && !flagged) {
+                        unsigned *dst = (unsigned *)(codes + __mul24(r * 2 + end, CS)) + 4 * c;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const unsigned x = (z >> (2 * q)) & 0x03030303u;       // A 0, C 1, T 2, G 3 ...
+                            dst[q] = x ^ ((x >> 1) & 0x01010101u);               // ... -> the kernels' A 0, C 1, G 2, T 3
+                        }
+                    } else {   // the same 16 window bytes from the ASCII buffer (any 16-byte piece of that end: all get visited)
+                        const uint4 v = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (end ? S : 0) + 16 * c);
+                        encode_bytes(r, L, (end ? S : 0) + 16 * c, v);
+                    }
+                }
+            } else if ((S & 15) == 0) {
                 // fast path: chunks never straddle the head/tail boundary; items are ordered [all head chunks]
                 // [all tail chunks] so that a wave is (almost always) uniform in role.  Full windows (len >= S):
                 // four LUT lookups -> one packed dword store; the head is written reversed (reverse complement).
@@ -2212,7 +2238,7 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
                                 smx_op *d_extra, uint32_t extra_cap, uint32_t *d_n_extra, uint64_t *d_counts,
                                 smx_hit *d_hits, int8_t *d_bdist, unsigned *d_tile_counter, int use_slots,
                                 const unsigned *d_pre, uint32_t npad, const smx::DemuxAux *aux_in) {
-    smx::DemuxAux aux = {nullptr, nullptr, 0, 0, 0, 0};
+    smx::DemuxAux aux = {nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr};
     if (aux_in) aux = *aux_in;
     if (aux.nitems > 0 && (use_slots || !d_pre || !aux.match || !aux.ovf_list || aux.nitems > 256)) return (int)hipErrorInvalidValue;
     if (aux.redo && (!aux.ovf_list || aux.Rc < 1)) return (int)hipErrorInvalidValue;

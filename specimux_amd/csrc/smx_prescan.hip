@@ -1,7 +1,7 @@
 // smx_prescan.hip -- gfx950 kernels of the primer prescan (algorithm: smx_prescan_core.h).
 //
-// prescan_transpose_kernel: one 256-thread workgroup per tile of 1024 reads (32 groups of 32); LDS = the tile's packed
-//   2-bit codes (2 * S / 16 blocks of 33 dwords per group: 42 KB at search_len 80); memory bound (reads the windows once).
+// prescan_transpose_kernel: one 256-thread workgroup per sub-tile of 256 reads (8 groups of 32); LDS = the sub-tile's packed
+//   2-bit codes (2 * S / 16 x 8 blocks of 33 dwords: 11.6 KB at search_len 80); memory bound (reads the windows once).
 // prescan_dp_kernel: one wave per (tile, primer) -- the pattern letters are wave-uniform kernel-argument loads; its 64
 //   lanes are the tile's 32 groups x 2 ends.  No tile in LDS (a 4.6 KB scratch for the current / next column's
 //   base-occurrence words only): residency is set by registers.  A lane keeps the DP column (2 x rows), the rows' scratch
@@ -19,47 +19,74 @@
 namespace smx {
 
 // ---- transpose kernel: windows -> 2-bit planes, bit-sliced over the 32 reads of a group (layout: prescan_plane_word)
-// NT = 320 threads when the tile's 32 x (2 S / 16) blocks are a multiple of 320 (search_len 80: 320 blocks = exactly one
-// transpose pass of five waves instead of one full pass of four plus one with a single wave busy), else 256.
-template <int NT>
-__global__ __launch_bounds__(NT) void prescan_transpose_kernel(int S, const uint8_t *__restrict__ windows,
-                                                               const int32_t *__restrict__ lens, uint32_t n_reads, int stride,
-                                                               unsigned *__restrict__ gplanes, uint32_t ntiles) {
+// One 256-thread workgroup per SUB-TILE of 256 reads (8 groups; four sub-tiles fill one DP tile of 1024 reads): every lane
+// issues all of its 16-byte window loads at once (2 S / 16 per lane: the whole sub-tile is in flight after one instruction
+// burst), packs, stages in 10 KB of LDS, and 8 x (2 S / 16) lanes transpose one 32 x 32 bit block each.  Small workgroups on
+// purpose: a batch is ~3 000 sub-tiles against ~2 000 resident workgroups, so loads of one workgroup overlap the transposes
+// and stores of its neighbours -- with one workgroup per 1024-read tile the whole launch was a single load -> pack -> barrier ->
+// transpose -> store sequence per CU slot (no steady state: 748 tiles on 768 slots), at 2.9 TB/s.
+// Also written here, for the demux kernel (codes2 != nullptr): the same 2-bit codes row-major per read in DP order
+// (codes2_word) -- it no longer reads the ASCII windows of reads whose windows are pure upper-case ACGT -- and one flag byte
+// per read: 1 = a window holds something else (naflag; such reads take the demux kernel's ASCII path and its scalar scan).
+constexpr int PRE_TNT = 256;
+__global__ __launch_bounds__(PRE_TNT) void prescan_transpose_kernel(int S, const uint8_t *__restrict__ windows,
+                                                                    const int32_t *__restrict__ lens, uint32_t n_reads, int stride,
+                                                                    unsigned *__restrict__ gplanes, unsigned *__restrict__ codes2,
+                                                                    uint8_t *__restrict__ naflag, uint32_t nsub) {
     extern __shared__ __attribute__((aligned(16))) unsigned plds[];
+    constexpr int NT = PRE_TNT, SUBR = PRE_SUBG * 32;
     const int tid = threadIdx.x;
     const int CH = S >> 4, ppr = 2 * CH;
     unsigned *planes = plds;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t r0 = tile * PRE_TILE;
-        // ---- phase 1: the tile's windows are one contiguous run of 16-byte pieces (stride = ppr * 16): plain streaming
-        // loads, eight in flight per lane
+    unsigned *flagL = plds + ppr * PRE_CS;   // [SUBR] per read: non-zero = not pure ACGT
+    for (uint32_t sub = blockIdx.x; sub < nsub; sub += gridDim.x) {
+        const uint32_t r0 = sub * SUBR;
+        flagL[tid] = 0u;
+        __syncthreads();
+        // ---- phase 1: the sub-tile's windows are one contiguous run of 16-byte pieces (stride = ppr * 16); piece q = (read
+        // q / ppr, piece c = q % ppr); lane tid takes pieces tid + u * NT, u < ppr
         {
-            const int npieces = PRE_TILE * ppr;
             int read = tid / ppr, c = tid - read * ppr;
             const int dr = NT / ppr, dc = NT - dr * ppr;
             const uint4 *src = (const uint4 *)(windows + (size_t)r0 * stride);
-            if (r0 + PRE_TILE <= n_reads) {   // whole tile in range (all but the last): no per-load guard, so that the
-                                              // compiler keeps a batch of loads in flight instead of one per branch
-                // npieces = 1024 * ppr is a multiple of 8 * NT (ppr is even): eight unconditional loads per batch.  (With a
-                // bounds test per load the compiler waits for each load before it branches to the next: 40 serial round trips.)
-                for (int q0 = tid; q0 < npieces; q0 += 8 * NT) {
-                    uint4 v[8];
+            unsigned *c2 = codes2 ? codes2 + (size_t)r0 * ppr : nullptr;
+            auto piece = [&](const uint4 &v) {
+                const unsigned bad = acgt_mismatch(v.x) | acgt_mismatch(v.y) | acgt_mismatch(v.z) | acgt_mismatch(v.w);
+                if (bad) flagL[read] = 1u;
+                const unsigned z = prescan_store_piece(planes, read, c, v.x, v.y, v.z, v.w);
+                if (c2) {
+                    int end, chunk;
+                    const unsigned zz = codes2_from_piece(z, c, CH, &end, &chunk);
+                    c2[codes2_word((size_t)read, CH, end, chunk)] = zz;
+                }
+                read += dr; c += dc;
+                if (c >= ppr) { c -= ppr; read++; }
+            };
+            if (r0 + SUBR <= n_reads) {   // whole sub-tile in range (all but the last): unconditional loads, issued in bursts
+                int u0 = 0;
+                for (; u0 + 10 <= ppr; u0 += 10) {
+                    uint4 v[10];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) v[u] = src[q0 + u * NT];
+                    for (int u = 0; u < 10; u++) v[u] = src[tid + (u0 + u) * NT];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        prescan_store_piece(planes, read, c, ppr, v[u].x, v[u].y, v[u].z, v[u].w);
-                        read += dr; c += dc;
-                        if (c >= ppr) { c -= ppr; read++; }
-                    }
+                    for (int u = 0; u < 10; u++) piece(v[u]);
+                }
+                for (; u0 + 2 <= ppr; u0 += 2) {   // (ppr is even)
+                    uint4 v[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) v[u] = src[tid + (u0 + u) * NT];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) piece(v[u]);
                 }
             } else {
-                for (int q = tid; q < npieces; q += NT) {
+                for (int u = 0; u < ppr; u++) {
                     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (r0 + (uint32_t)read < n_reads) v = src[q];
-                    prescan_store_piece(planes, read, c, ppr, v.x, v.y, v.z, v.w);
-                    read += dr; c += dc;
-                    if (c >= ppr) { c -= ppr; read++; }
+                    const bool in = r0 + (uint32_t)read < n_reads;
+                    if (in) v = src[tid + u * NT];
+                    unsigned *keep = c2;
+                    if (!in) c2 = nullptr;   // (no codes2 rows beyond the batch)
+                    piece(v);
+                    c2 = keep;
                 }
             }
         }
@@ -67,39 +94,43 @@ __global__ __launch_bounds__(NT) void prescan_transpose_kernel(int S, const uint
         // ---- phase 1b: reads shorter than the window (rare): their head pieces again, right-aligned
         // (prescan_short_head_piece); kept out of the streaming loop, where the length load would sit in front of a branch
         {
-            constexpr int NL = (PRE_TILE + NT - 1) / NT;
-            int Ls[NL];
-#pragma unroll
-            for (int u = 0; u < NL; u++) {   // all length loads first
-                const uint32_t rd = r0 + (uint32_t)(tid + u * NT);
-                Ls[u] = lens[rd < n_reads ? rd : n_reads - 1];
-            }
-#pragma unroll
-            for (int u = 0; u < NL; u++) {
-                const int read = tid + u * NT;
-                if (read < PRE_TILE && r0 + (uint32_t)read < n_reads && Ls[u] < S) {
-                    const uint8_t *row = windows + (size_t)(r0 + (uint32_t)read) * stride;
+            const uint32_t rd = r0 + (uint32_t)tid;
+            const int L = lens[rd < n_reads ? rd : n_reads - 1];
+            if (rd < n_reads) {
+                if (naflag) naflag[rd] = (uint8_t)(flagL[tid] != 0u);
+                if (L < S) {
+                    const uint8_t *row = windows + (size_t)rd * stride;
                     for (int c = 0; c < CH; c++) {
                         unsigned w4[4];
-                        prescan_short_head_piece(row, c, S, Ls[u], w4);
-                        prescan_store_piece(planes, read, c, ppr, w4[0], w4[1], w4[2], w4[3]);
+                        prescan_short_head_piece(row, c, S, L, w4);
+                        const unsigned z = prescan_store_piece(planes, tid, c, w4[0], w4[1], w4[2], w4[3]);
+                        if (codes2) {
+                            int end, chunk;
+                            const unsigned zz = codes2_from_piece(z, c, CH, &end, &chunk);
+                            codes2[codes2_word((size_t)rd, CH, end, chunk)] = zz;
+                        }
                     }
                 }
             }
         }
         __syncthreads();
-        // ---- phase 2: bit transposes, one block per lane and round; 8 x 16-byte stores per block
-        uint4 *gp = (uint4 *)(gplanes + (size_t)tile * CH * 8 * 64 * 4);
-        for (int b2 = tid; b2 < PRE_G * ppr; b2 += NT) {   // b2 = c * 32 + g: 32 consecutive lanes store 32 consecutive groups
-            const int c = b2 >> 5, g = b2 & 31;
-            unsigned o[32];
-            prescan_transpose_block(planes, g * ppr + c, c, CH, o);
-            const int chunk = prescan_block_chunk(c, CH), lane = prescan_block_lane(g, c, CH);
+        // ---- phase 2: bit transposes, one block per lane; 8 x 16-byte stores per block.  Lane -> (piece c fastest, group g):
+        // the 32 lanes of a half-wave read 32 different LDS banks (smx_prescan_core.h PRE_CS)
+        {
+            const uint32_t tile = sub >> 2;
+            const int g0 = (int)(sub & 3u) * PRE_SUBG;
+            uint4 *gp = (uint4 *)(gplanes + (size_t)tile * CH * 8 * 64 * 4);
+            for (int b2 = tid; b2 < PRE_SUBG * ppr; b2 += NT) {
+                const int g = b2 / ppr, c = b2 - g * ppr;
+                unsigned o[32];
+                prescan_transpose_block(planes, g, c, CH, o);
+                const int chunk = prescan_block_chunk(c, CH), lane = prescan_block_lane(g0 + g, c, CH);
 #pragma unroll
-            for (int q = 0; q < 8; q++)
-                gp[((size_t)chunk * 64 + lane) * 8 + q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+                for (int q = 0; q < 8; q++)
+                    gp[((size_t)chunk * 64 + lane) * 8 + q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+            }
         }
-        __syncthreads();   // the next tile's phase 1 rewrites the staging blocks
+        __syncthreads();   // the next sub-tile's phase 1 rewrites the staging blocks
     }
 }
 
@@ -116,10 +147,16 @@ __global__ __launch_bounds__(64, SMX_PRE_WAVES) void prescan_dp_kernel(PreDesc D
     __shared__ unsigned scratch[PRE_SCRATCH];
     const int lane = threadIdx.x;
     const int CH = D.S >> 4;
-    const uint32_t nwork = ntiles * (uint32_t)D.NP;
+    // work item -> (tile, primer): the NP waves of one tile read the same planes, so they get workgroup ids that are equal
+    // mod 8 -- blocks b and b + 8 share an XCD (and its L2) -- and close together: item = (group of 8 tiles, primer, tile in
+    // the group).  Speed only: with consecutive ids the planes of every tile were fetched from HBM once per primer.
+    const uint32_t per8 = 8u * (uint32_t)D.NP;
+    const uint32_t nwork = ((ntiles + 7u) >> 3) * per8;
     for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const uint32_t tile = wi / (uint32_t)D.NP;
-        const int p = (int)(wi - tile * (uint32_t)D.NP);
+        const uint32_t grp = wi / per8, rem = wi - grp * per8;
+        const uint32_t tile = grp * 8u + (rem & 7u);
+        const int p = (int)(rem >> 3);
+        if (tile >= ntiles) continue;
         const int g = lane >> 1, X = lane & 1;
         // tile-major output: the CH x 2 NP words of a read sit within its tile's 4 * 2 NP * CH KB
         prescan_dp<MR, NX, MT>(gplanes + (size_t)tile * CH * 8 * 64 * 4, scratch, lane, CH, D, p,
@@ -130,12 +167,10 @@ __global__ __launch_bounds__(64, SMX_PRE_WAVES) void prescan_dp_kernel(PreDesc D
 
 }  // namespace smx
 
-// the streaming phase wants 1024 x pieces-per-read to be a multiple of 8 x threads, the transpose phase 32 x pieces-per-read
-// blocks a multiple of the threads: 320 threads when pieces-per-read (2 S / 16) is a multiple of 10
-extern "C" int smx_prescan_transpose_threads(int S) { return ((2 * (S >> 4)) % 10) == 0 ? 320 : 256; }
+extern "C" int smx_prescan_transpose_threads(int S) { (void)S; return smx::PRE_TNT; }
 
-extern "C" size_t smx_prescan_lds_bytes(int S) {   // the transpose kernel's staging blocks
-    return ((size_t)smx::PRE_G * (2 * (S >> 4)) * smx::PRE_BLK + 64) * 4;
+extern "C" size_t smx_prescan_lds_bytes(int S) {   // the transpose kernel's staging blocks + one flag word per read of the sub-tile
+    return ((size_t)(2 * (S >> 4)) * smx::PRE_CS + smx::PRE_SUBG * 32) * 4;
 }
 
 #define SMX_PRE_VARIANTS(X) X(22, 0) X(22, 4) X(24, 0) X(24, 4) X(31, 0) X(31, 4)
@@ -153,16 +188,14 @@ static const void *prescan_fn(int mr, int nx) {
 // grid_t / grid_d = resident workgroups of the two kernels (the caller sizes them); d_match = nullptr: no match words
 extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int grid_t, size_t lds_t, int grid_d, void *stream,
                                   const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride,
-                                  unsigned *d_planes, unsigned *d_out, unsigned *d_match, void *ev_mid) {
+                                  unsigned *d_planes, unsigned *d_out, unsigned *d_match, void *ev_mid, unsigned *d_codes2,
+                                  uint8_t *d_naflag) {
     static_assert(smx::PRE_MAXROWS == 31 && smx::PRE_MAXSYM == 8, "variant table");
     const uint32_t ntiles = (n_reads + smx::PRE_TILE - 1) / smx::PRE_TILE;
+    const uint32_t nsub = ntiles * (smx::PRE_G / smx::PRE_SUBG);   // every sub-tile of the last tile: the DP kernel reads whole tiles
     hipStream_t s = (hipStream_t)stream;
-    if (smx_prescan_transpose_threads(D->S) == 320)
-        hipLaunchKernelGGL(smx::prescan_transpose_kernel<320>, dim3(grid_t), dim3(320), lds_t, s, D->S, d_windows, d_lens, n_reads,
-                           stride, d_planes, ntiles);
-    else
-        hipLaunchKernelGGL(smx::prescan_transpose_kernel<256>, dim3(grid_t), dim3(256), lds_t, s, D->S, d_windows, d_lens, n_reads,
-                           stride, d_planes, ntiles);
+    hipLaunchKernelGGL(smx::prescan_transpose_kernel, dim3(grid_t), dim3(smx::PRE_TNT), lds_t, s, D->S, d_windows, d_lens, n_reads,
+                       stride, d_planes, d_codes2, d_naflag, nsub);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);   // diagnostic: boundary between the two kernels
@@ -180,15 +213,12 @@ extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int gri
 }
 
 extern "C" int smx_prescan_set_lds_limit(size_t bytes) {
-    hipError_t e = hipFuncSetAttribute((const void *)smx::prescan_transpose_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    hipError_t e2 = hipFuncSetAttribute((const void *)smx::prescan_transpose_kernel<320>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return (int)(e != hipSuccess ? e : e2);
+    return (int)hipFuncSetAttribute((const void *)smx::prescan_transpose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 extern "C" int smx_prescan_occupancy(int S, int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d) {
-    const int nt = smx_prescan_transpose_threads(S);
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        blocks_t, nt == 320 ? (const void *)smx::prescan_transpose_kernel<320> : (const void *)smx::prescan_transpose_kernel<256>, nt, lds_t);
+    (void)S;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_t, (const void *)smx::prescan_transpose_kernel, smx::PRE_TNT, lds_t);
     if (e != hipSuccess) return (int)e;
     return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_d, prescan_fn(mr, nx), 64, 0);
 }

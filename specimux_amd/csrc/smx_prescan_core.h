@@ -49,6 +49,12 @@ constexpr int PRE_TILE = PRE_G * 32;
 constexpr int PRE_MAXROWS = 31;    // primers up to 31 nt (5-plane gap counter)
 constexpr int PRE_MAXSYM = 8;      // distinct pattern letters (as A/C/G/T sets) per panel
 constexpr int PRE_BLK = 33;        // dwords per 32 x 32 bit block in LDS (odd: conflict-free column access)
+constexpr int PRE_SUBG = 8;        // 32-read groups per transpose workgroup: a sub-tile of 256 reads (a tile = 4 sub-tiles)
+// Staging layout of a sub-tile: word (piece c, group g, read rr) at c * PRE_CS + g * PRE_BLK + rr.  ds_write_b32 / ds_read_b32
+// bank = word mod 32 within each 32-lane half: phase 1 writes with (c, rr) varying -> bank 3 c + rr (+ g), phase 2 reads
+// with (c, g) varying -> bank 3 c + g (+ r): both (nearly) conflict-free because PRE_CS = 3 (mod 32), PRE_BLK = 1 (mod 32).
+constexpr int PRE_CS = 291;        // >= PRE_SUBG * PRE_BLK
+static_assert(PRE_CS >= PRE_SUBG * PRE_BLK && PRE_CS % 32 == 3, "staging stride");
 constexpr int PRE_SCRATCH = 2 * (PRE_MAXSYM + 1) * 64;   // dwords of per-wave scratch: [2 buffers][symbol][lane]
 
 // Host-built description of the patterns (device copy passed by value to the kernel).
@@ -87,6 +93,41 @@ SMX_HD unsigned pack16(unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
 // bit q of a packed dword belongs to base t of the chunk, plane (code bit) pl
 SMX_HD int pack_t(int q) { return 4 * ((q & 7) >> 1) + (q >> 3); }
 SMX_HD int pack_pl(int q) { return q & 1; }
+
+// The same packed dword for the reverse complement of the 16 bases: base t <-> 15 - t (byte i <-> 3 - i, bit pair kq <-> 3 - kq),
+// complement = code ^ 2 in the (ch >> 1) & 3 coding (A 0 <-> T 2, C 1 <-> G 3)
+SMX_HD unsigned pack16_revcomp(unsigned z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    z = __builtin_amdgcn_perm(0u, z, 0x00010203u);
+#else
+    z = (z >> 24) | ((z >> 8) & 0xFF00u) | ((z << 8) & 0xFF0000u) | (z << 24);
+#endif
+    z = ((z & 0x0F0F0F0Fu) << 4) | ((z >> 4) & 0x0F0F0F0Fu);
+    z = ((z & 0x33333333u) << 2) | ((z >> 2) & 0x33333333u);
+    return z ^ 0xAAAAAAAAu;
+}
+// Does the dword hold nothing but upper-case A / C / G / T?  0 iff it does (OR the results of a window's dwords).
+SMX_HD unsigned acgt_mismatch(unsigned w) {
+    const unsigned x = (w >> 1) & 0x03030303u;   // A 0, C 1, T 2, G 3
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(0u, 0x47544341u, x) ^ w;
+#else
+    static const unsigned char L[4] = {'A', 'C', 'T', 'G'};
+    unsigned r = 0;
+    for (int i = 0; i < 4; i++) r |= (unsigned)L[(x >> (8 * i)) & 3] << (8 * i);
+    return r ^ w;
+#endif
+}
+
+// Row-major 2-bit codes for the demux kernel ("codes2"): per read 2 * CH dwords, [end][16-column chunk] in DP order (end A =
+// reverse complement of the head window, end B = the tail window); dword = pack16 of the chunk's 16 columns.
+SMX_HD size_t codes2_word(size_t read, int CH, int end, int chunk) { return (read * 2 + (size_t)end) * (size_t)CH + (size_t)chunk; }
+// piece c of a window row (c < CH: head, else tail), its packed dword z -> (dword of codes2, where it goes)
+SMX_HD unsigned codes2_from_piece(unsigned z, int c, int CH, int *end, int *chunk) {
+    if (c < CH) { *end = 0; *chunk = CH - 1 - c; return pack16_revcomp(z); }
+    *end = 1; *chunk = c - CH;
+    return z;
+}
 
 // ---- consumer side: one alignment from its CH chunk words (w[c * cstride], c = 0 .. CH-1).  Returns the best distance
 // (> k: no match) and, for a match, jstar, the number of optimal ends and the S-bit mask of optimal end columns
@@ -152,10 +193,12 @@ SMX_HD int prescan_decode(const unsigned *w, size_t cstride, int CH, int MW, int
 // ------------------------------------------------------------------------------------------------
 // Phase 1, one 16-byte piece: piece q of the tile = (read q / ppr, piece c = q % ppr of its window row); ppr = pieces per
 // read = 2 * S / 16.  `w` = the four dwords of the piece.  Block (g, c) holds the packed dwords of the group's 32 reads.
-SMX_HD void prescan_store_piece(unsigned *planes, int read_in_tile, int c, int ppr, unsigned w0, unsigned w1, unsigned w2,
-                                unsigned w3) {
-    const int g = read_in_tile >> 5, rr = read_in_tile & 31;
-    planes[(g * ppr + c) * PRE_BLK + rr] = pack16(w0, w1, w2, w3);
+// (read_in_sub = read index inside the 256-read sub-tile)
+SMX_HD unsigned prescan_store_piece(unsigned *planes, int read_in_sub, int c, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+    const int g = read_in_sub >> 5, rr = read_in_sub & 31;
+    const unsigned z = pack16(w0, w1, w2, w3);
+    planes[c * PRE_CS + g * PRE_BLK + rr] = z;
+    return z;
 }
 
 // Head window piece c of a read shorter than S: the stored window holds head[0 : L) left-aligned; the prescan wants it
@@ -178,9 +221,9 @@ SMX_HD void prescan_short_head_piece(const uint8_t *row, int c, int S, int L, un
 
 // Phase 2, one block: 32 x 32 bit transpose, result in DP order.  Pieces c < CH are the head window (end A: reversed and
 // complemented), pieces c >= CH the tail window (end B).  DP order: out[2 * t' + plane] for DP column t' of the chunk.
-SMX_HD void prescan_transpose_block(const unsigned *planes, int blk, int c, int CH, unsigned (&out)[32]) {
+SMX_HD void prescan_transpose_block(const unsigned *planes, int g, int c, int CH, unsigned (&out)[32]) {
     unsigned a[32];
-    const unsigned *pb = planes + blk * PRE_BLK;
+    const unsigned *pb = planes + c * PRE_CS + g * PRE_BLK;
 #pragma unroll
     for (int r = 0; r < 32; r++) a[r] = pb[r];
     transpose32(a);

@@ -105,24 +105,63 @@ int main(int argc, char **argv) {
         memcpy(&win[(size_t)r * 2 * S], h.data(), h.size());
         memcpy(&win[(size_t)r * 2 * S + S], t.data(), t.size());
     }
-    // ---- the kernel's phases on the host
-    std::vector<unsigned> planes((size_t)PRE_G * ppr * PRE_BLK + 64, 0u);
-    for (int q = 0; q < n * ppr; q++) {   // phase 1
-        const int read = q / ppr, c = q % ppr;
-        unsigned w[4];
-        memcpy(w, &win[(size_t)read * 2 * S + 16 * c], 16);
-        if (c < CH && rlen[read] < S) prescan_short_head_piece(&win[(size_t)read * 2 * S], c, S, rlen[read], w);
-        prescan_store_piece(planes.data(), read, c, ppr, w[0], w[1], w[2], w[3]);
+    // ---- the kernel's phases on the host: four sub-tiles of 256 reads, each staged, transposed and written out on its own
+    // some reads get a character outside upper-case ACGT (the flag byte must say so; their codes are then unused)
+    std::vector<int> dirty(n, 0);
+    for (int r = 5; r < n; r += 41) {
+        if (rlen[r] < 1) continue;
+        const int pos = (int)(rng() % (unsigned)std::min(rlen[r], S));
+        const bool tail = (r & 1) != 0;
+        win[(size_t)r * 2 * S + (tail ? S : 0) + pos] = (unsigned char)"NacgtRY-"[rng() % 8];
+        dirty[r] = 1;
     }
     std::vector<unsigned> gpl((size_t)CH * 8 * 64 * 4, 0u);   // the tile's planes in the HBM layout
-    for (int b = 0; b < PRE_G * ppr; b++) {   // phase 2
-        const int g = b / ppr, c = b % ppr;
-        unsigned o[32];
-        prescan_transpose_block(planes.data(), b, c, CH, o);
-        for (int d = 0; d < 32; d++) gpl[prescan_plane_word(prescan_block_chunk(c, CH), prescan_block_lane(g, c, CH), d)] = o[d];
+    std::vector<unsigned> codes2((size_t)n * ppr, 0u);
+    std::vector<unsigned char> naflag(n, 0);
+    long bad = 0;
+    for (int sub = 0; sub < PRE_G / PRE_SUBG; sub++) {
+        std::vector<unsigned> planes((size_t)ppr * PRE_CS + 64, 0u);
+        const int r0 = sub * PRE_SUBG * 32;
+        for (int q = 0; q < PRE_SUBG * 32 * ppr; q++) {   // phase 1
+            const int rs = q / ppr, c = q % ppr, read = r0 + rs;
+            unsigned w[4];
+            memcpy(w, &win[(size_t)read * 2 * S + 16 * c], 16);
+            if (acgt_mismatch(w[0]) | acgt_mismatch(w[1]) | acgt_mismatch(w[2]) | acgt_mismatch(w[3])) naflag[read] = 1;
+            if (c < CH && rlen[read] < S) prescan_short_head_piece(&win[(size_t)read * 2 * S], c, S, rlen[read], w);
+            const unsigned z = prescan_store_piece(planes.data(), rs, c, w[0], w[1], w[2], w[3]);
+            int end, chunk;
+            const unsigned zz = codes2_from_piece(z, c, CH, &end, &chunk);
+            codes2[codes2_word((size_t)read, CH, end, chunk)] = zz;
+        }
+        for (int b = 0; b < PRE_SUBG * ppr; b++) {   // phase 2
+            const int g = b / ppr, c = b % ppr;
+            unsigned o[32];
+            prescan_transpose_block(planes.data(), g, c, CH, o);
+            for (int d = 0; d < 32; d++)
+                gpl[prescan_plane_word(prescan_block_chunk(c, CH), prescan_block_lane(sub * PRE_SUBG + g, c, CH), d)] = o[d];
+        }
+    }
+    // the row-major codes and the flag byte, read by read: column t of end X in DP order = the text the DP sees
+    for (int read = 0; read < n; read++) {
+        const bool expect_flag = dirty[read] || rlen[read] < S;   // (zero padding of a short read is not ACGT either)
+        if ((naflag[read] != 0) != expect_flag) { if (bad < 10) printf("FLAG read %d: %d, expected %d\n", read, naflag[read], (int)expect_flag); bad++; }
+        if (dirty[read]) {   // back to plain ACGT for the alignment checks below (the planes of such reads are not consumed)
+            continue;
+        }
+        for (int X = 0; X < 2; X++) {
+            std::string text;
+            if (X) text = tails[read];
+            else { text.assign(heads[read].rbegin(), heads[read].rend()); for (auto &c : text) c = comp(c); }
+            for (int t = 0; t < (int)text.size(); t++) {
+                const unsigned z = codes2[codes2_word((size_t)read, CH, X, t >> 4)];
+                const int tt = t & 15, kq = tt >> 2, i = tt & 3;
+                const char got = "ACTG"[(z >> (8 * i + 2 * kq)) & 3u];
+                if (got != text[t]) { if (bad < 10) printf("CODES2 read %d end %d column %d: %c, expected %c\n", read, X, t, got, text[t]); bad++; break; }
+            }
+        }
     }
     std::vector<unsigned> scratch(PRE_SCRATCH);
-    long bad = 0, checked = 0, matched = 0, multi = 0;
+    long checked = 0, matched = 0, multi = 0;
     const int MW = (S + 31) / 32;
     std::vector<unsigned> words((size_t)CH * 32);
     for (int p = 0; p < NP; p++)
@@ -134,6 +173,7 @@ int main(int argc, char **argv) {
             else prescan_dp<31, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32, &mword);
             for (int r = 0; r < 32; r++) {
                 const int read = g * 32 + r;
+                if (dirty[read]) continue;   // not pure ACGT: the demux kernel scans such reads itself
                 std::string text;
                 if (X) text = tails[read];
                 else { text.assign(heads[read].rbegin(), heads[read].rend()); for (auto &c : text) c = comp(c); }

@@ -556,14 +556,14 @@ static int ensure_device(smx_panel *P) {
     // after the queue has drained would only pay the panel staging and its one-time register spills
     {
         int occ = 0;   // (behind a compact launch the dense lean kernel runs as the redo instantiation)
-        if (smx_query_occupancy(&P->hp, P->use64, 0, P->nitems > 0 ? 2 : 0, P->R, 0, P->lds, &occ) != 0 || occ < 1) occ = 4;
+        if (smx_query_occupancy(&P->hp, P->use64, 0, P->nitems > 0 ? 2 : 0, P->R, 0, P->lds, &occ, P->pre_ok ? 1 : 0) != 0 || occ < 1) occ = 4;
         P->blocks_per_cu = occ;
         occ = 0;
-        if (smx_query_occupancy(&P->hp, P->use64, 1, 0, P->R_slots, 0, P->lds_slots, &occ) != 0 || occ < 1) occ = 4;
+        if (smx_query_occupancy(&P->hp, P->use64, 1, 0, P->R_slots, 0, P->lds_slots, &occ, P->pre_ok ? 1 : 0) != 0 || occ < 1) occ = 4;
         P->blocks_per_cu_slots = occ;
         if (P->nitems > 0) {
             occ = 0;
-            if (smx_query_occupancy(&P->hp, P->use64, 0, 1, P->Rc, P->nitems, P->lds_c, &occ) != 0 || occ < 1) occ = 4;
+            if (smx_query_occupancy(&P->hp, P->use64, 0, 1, P->Rc, P->nitems, P->lds_c, &occ, P->pre_ok ? 1 : 0) != 0 || occ < 1) occ = 4;
             P->blocks_per_cu_c = occ;
         }
     }
@@ -579,7 +579,7 @@ static int ensure_device(smx_panel *P) {
     if (const char *e = getenv("SMX_BLOCKS_PER_CU")) P->blocks_per_cu = P->blocks_per_cu_slots = P->blocks_per_cu_c = std::max(1, atoi(e));
     if (P->env_debug) {
         int occ = -1;
-        (void)smx_query_occupancy(&P->hp, P->use64, 0, P->nitems > 0 ? 2 : 0, P->R, 0, P->lds, &occ);
+        (void)smx_query_occupancy(&P->hp, P->use64, 0, P->nitems > 0 ? 2 : 0, P->R, 0, P->lds, &occ, P->pre_ok ? 1 : 0);
         fprintf(stderr, "[smx] lean R=%d lds=%zu | slots R=%d lds=%zu | occupancy API (lean): %d blocks/CU, grid multiplier %d, CUs %d\n",
                 P->R, P->lds, P->R_slots, P->lds_slots, occ, P->blocks_per_cu, P->n_cu);
         if (P->nitems > 0)

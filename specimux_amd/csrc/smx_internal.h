@@ -81,7 +81,7 @@ size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, in
                            int slots, int bs, int nitems, int ncand);
 int smx_set_demux_lds_limit(int use64, size_t bytes);
 int smx_query_occupancy(const smx::DevPanel *P, int use64, int use_slots, int cm, int R, int nitems, size_t lds_bytes,
-                        int *blocks_per_cu);
+                        int *blocks_per_cu, int have_prescan);
 int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,
                      const unsigned char *d_tcodes, int n, int k, int mode, int *d_dist, unsigned char *d_endflag,
                      int *d_starts);

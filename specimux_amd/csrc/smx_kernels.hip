@@ -1974,7 +1974,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     }
                 }
             };
-            if ((S & 15) == 0 && aux.codes2 != nullptr) {
+            // (the default-flags kernels are only launched behind the prescan: their ASCII fast path is compiled out)
+            if ((S & 15) == 0 && (sp || aux.codes2 != nullptr)) {
                 // behind the prescan: the transpose kernel has already turned every pure-ACGT window into 2-bit codes, row-major
                 // per read and in DP order (end A reverse-complemented): one dword per (read, end, 16-column chunk), the tile's
                 // dwords contiguous.  Four shift/mask/swap steps spell the dword out as 16 code bytes.  Reads the transpose kernel
@@ -1986,9 +1987,8 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                     const unsigned z = c2[ci];
                     const int r = (int)__umulhi((unsigned)ci, permagic), rem = ci - __mul24(r, per);
                     const int end = rem >= hc ? 1 : 0, c = rem - (end ? hc : 0);
-                    const int L = lens[r0n + r];
-                    const unsigned flagged = aux.naflag[r0n + r];
-                    if (L >= S && !flagged) {
+                    const unsigned flagged = aux.naflag[r0n + r];   // 1: shorter than the window, or not pure upper-case ACGT
+                    if (!flagged) {
                         unsigned *dst = (unsigned *)(codes + __mul24(r * 2 + end, CS)) + 4 * c;
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
@@ -1997,10 +1997,10 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                         }
                     } else {   // the same 16 window bytes from the ASCII buffer (any 16-byte piece of that end: all get visited)
                         const uint4 v = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (end ? S : 0) + 16 * c);
-                        encode_bytes(r, L, (end ? S : 0) + 16 * c, v);
+                        encode_bytes(r, lens[r0n + r], (end ? S : 0) + 16 * c, v);
                     }
                 }
-            } else if ((S & 15) == 0) {
+            } else if (!sp && (S & 15) == 0) {
                 // fast path: chunks never straddle the head/tail boundary; items are ordered [all head chunks]
                 // [all tail chunks] so that a wave is (almost always) uniform in role.  Full windows (len >= S):
                 // four LUT lookups -> one packed dword store; the head is written reversed (reverse complement).
@@ -2032,7 +2032,7 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                         encode_bytes(r, L, (tail ? S : 0) + 16 * c, v);
                     }
                 }
-            } else {
+            } else if (!sp) {
                 const int chunks = stride / 16;
                 const uint4 *src = (const uint4 *)(windows + (size_t)r0n * stride);
                 for (int ci = wid; ci < nrn * chunks; ci += nw) {
@@ -2222,8 +2222,8 @@ int demux_bsv(const smx::DevPanel *P, int use_slots) {
 }
 // the default-flags specialisation applies to the k <= 3 lean kernel (not its tails variant, not the redo launch) with
 // 64-read tiles
-int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm, int R, int nitems) {
-    const bool flags = !use64 && bsv == 1 && cm != 2 && (cm == 0 || nitems == 256) && !P->cap_hits && !P->cap_ents &&
+int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm, int R, int nitems, bool have_codes2) {
+    const bool flags = have_codes2 && !use64 && bsv == 1 && cm != 2 && (cm == 0 || nitems == 256) && !P->cap_hits && !P->cap_ents &&
                        P->kidx == 3 && P->maxB <= 32 && !P->need_starts && P->trim == SMX_TRIM_BARCODES && P->derep == SMX_DEREP_BEST &&
                        P->preorient && P->minlen == -1 && P->maxlen == -1 && !P->dbg_phase && !(P->no_sp & 1);
     if (!flags) return 0;
@@ -2248,7 +2248,7 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
     // d_tile_counter = {tile queue head, overflow tiles, finished workgroups, extra records}: zero at allocation, re-armed
     // by the last workgroup of every launch (of the last launch of a chain).  Slots mode never uses the bit-sliced scan.
     const int bsv = demux_bsv(P, use_slots), cm = aux.nitems > 0 ? 1 : (aux.redo ? 2 : 0);
-    const void *fn = demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm, R, aux.nitems));
+    const void *fn = demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm, R, aux.nitems, aux.codes2 != nullptr && d_pre != nullptr));
     smx::DevPanel pv = *P;
     unsigned long long *counts = (unsigned long long *)d_counts;
     void *args[] = {&pv, &d_windows, &d_lens, &n_reads, &R, &d_ops, &d_extra, &extra_cap, &d_n_extra, &counts, &d_hits, &d_bdist,
@@ -2279,9 +2279,9 @@ extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
 
 // resident workgroups per CU of the kernel a launch with these parameters would use (cm: 0 dense, 1 compact, 2 redo)
 extern "C" int smx_query_occupancy(const smx::DevPanel *P, int use64, int use_slots, int cm, int R, int nitems, size_t lds_bytes,
-                                   int *blocks_per_cu) {
+                                   int *blocks_per_cu, int have_prescan) {
     const int bsv = demux_bsv(P, use_slots);
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm, R, nitems)),
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm, R, nitems, have_prescan != 0)),
                                                              256, lds_bytes);
 }
 

@@ -27,7 +27,8 @@ namespace smx {
 // transpose -> store sequence per CU slot (no steady state: 748 tiles on 768 slots), at 2.9 TB/s.
 // Also written here, for the demux kernel (codes2 != nullptr): the same 2-bit codes row-major per read in DP order
 // (codes2_word) -- it no longer reads the ASCII windows of reads whose windows are pure upper-case ACGT -- and one flag byte
-// per read: 1 = a window holds something else (naflag; such reads take the demux kernel's ASCII path and its scalar scan).
+// per read: 1 = a window holds something else, or the read is shorter than the window (naflag; such reads take the demux
+// kernel's ASCII path; the ones with other characters also its scalar scan).
 constexpr int PRE_TNT = 256;
 __global__ __launch_bounds__(PRE_TNT) void prescan_transpose_kernel(int S, const uint8_t *__restrict__ windows,
                                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int stride,
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(PRE_TNT) void prescan_transpose_kernel(int S, const
             const uint32_t rd = r0 + (uint32_t)tid;
             const int L = lens[rd < n_reads ? rd : n_reads - 1];
             if (rd < n_reads) {
-                if (naflag) naflag[rd] = (uint8_t)(flagL[tid] != 0u);
+                if (naflag) naflag[rd] = (uint8_t)(flagL[tid] != 0u || L < S);   // 1: the demux kernel encodes this read from ASCII
                 if (L < S) {
                     const uint8_t *row = windows + (size_t)rd * stride;
                     for (int c = 0; c < CH; c++) {

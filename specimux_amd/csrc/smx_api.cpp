@@ -146,7 +146,6 @@ struct smx_panel {
     bool pre_ok = false;
     smx::PreDesc pre;
     int pre_mr = 24, pre_nx = 0, pre_blocks_t = 1, pre_blocks_d = 8;   // longest primer, degenerate symbols, residency
-    int pre_rs = 1;                          // row-split DP kernel (two lanes per problem); SMX_DP_RS=0: one lane per problem
     size_t pre_lds = 0;                      // transpose kernel staging
     DevBuf pre_planes[SMX_MAX_STREAMS];      // per stream slot: the 2-bit text planes of the batch (read-tile major)
     DevBuf pre_recs[SMX_MAX_STREAMS];
@@ -259,7 +258,6 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
             P->pre_mr = maxm;
             P->pre_nx = P->pre.nsym - 4;
             P->pre_lds = smx_prescan_lds_bytes(h.S);
-            if (const char *e = getenv("SMX_DP_RS")) P->pre_rs = atoi(e) != 0;
             if (P->pre_lds > 160 * 1024) P->pre_ok = false;
         }
     }
@@ -573,7 +571,7 @@ static int ensure_device(smx_panel *P) {
         if (P->pre_lds > 64 * 1024 && smx_prescan_set_lds_limit(P->pre_lds) != 0)
             return fail(SMX_ERR_DEVICE, "cannot raise the prescan kernel's dynamic LDS limit to %zu bytes", P->pre_lds);
         int occ_t = 0, occ_d = 0;
-        if (smx_prescan_occupancy(P->hp.S, P->pre_mr, P->pre_nx, P->pre_lds, &occ_t, &occ_d, P->pre_rs) != 0 || occ_t < 1 || occ_d < 1) { occ_t = 1; occ_d = 8; }
+        if (smx_prescan_occupancy(P->hp.S, P->pre_mr, P->pre_nx, P->pre_lds, &occ_t, &occ_d) != 0 || occ_t < 1 || occ_d < 1) { occ_t = 1; occ_d = 8; }
         P->pre_blocks_t = occ_t;
         P->pre_blocks_d = occ_d;
         if (P->env_debug) fprintf(stderr, "[smx] prescan: transpose %d workgroups/CU (lds %zu), DP %d waves/CU\n", occ_t, P->pre_lds, occ_d);
@@ -657,13 +655,12 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         // which balances better than ~2.3 loop iterations per resident workgroup
         const int grid_t = (int)(ptiles * (smx::PRE_G / smx::PRE_SUBG));
         // (DP work items come in groups of 8 tiles x NP primers; grid a multiple of 8: blocks b and b + 8 share an XCD)
-        const int grid_d = (int)std::min<uint32_t>(((ptiles + 7) / 8) * 8 * (uint32_t)P->hp.NP * (P->pre_rs ? 2u : 1u),
-                                                   (uint32_t)(P->n_cu * P->pre_blocks_d));
+        const int grid_d = (int)std::min<uint32_t>(((ptiles + 7) / 8) * 8 * (uint32_t)P->hp.NP, (uint32_t)(P->n_cu * P->pre_blocks_d));
         d_codes2 = (const unsigned *)pc.p;
         d_naflag = (const uint8_t *)pc.p + codes_bytes;
         int pe = smx_launch_prescan(&P->pre, P->pre_mr, P->pre_nx, grid_t, P->pre_lds, grid_d, stream, d_windows, d_lens, n_reads,
                                     P->hp.wstride, (unsigned *)pp.p, (unsigned *)pb.p, P->nitems > 0 ? (unsigned *)pm.p : nullptr,
-                                    P->kev_on ? (void *)P->kev[1] : nullptr, (unsigned *)pc.p, (uint8_t *)pc.p + codes_bytes, P->pre_rs);
+                                    P->kev_on ? (void *)P->kev[1] : nullptr, (unsigned *)pc.p, (uint8_t *)pc.p + codes_bytes);
         if (pe != 0) return fail(SMX_ERR_DEVICE, "prescan kernel launch failed: %s", hipGetErrorString((hipError_t)pe));
         d_pre = (const unsigned *)pb.p;
         if (P->kev_on) (void)hipEventRecord(P->kev[2], (hipStream_t)stream);

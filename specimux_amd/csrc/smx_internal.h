@@ -73,9 +73,9 @@ int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t 
 size_t smx_prescan_lds_bytes(int S);
 int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int grid_t, size_t lds_t, int grid_d, void *stream,
                        const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride, unsigned *d_planes,
-                       unsigned *d_out, unsigned *d_match, void *ev_mid, unsigned *d_codes2, uint8_t *d_naflag, int rs);
+                       unsigned *d_out, unsigned *d_match, void *ev_mid, unsigned *d_codes2, uint8_t *d_naflag);
 int smx_prescan_set_lds_limit(size_t bytes);
-int smx_prescan_occupancy(int S, int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d, int rs);
+int smx_prescan_occupancy(int S, int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d);
 int smx_prescan_transpose_threads(int S);
 size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta, int kidx,
                            int slots, int bs, int nitems, int ncand);

@@ -169,34 +169,6 @@ __global__ __launch_bounds__(64, SMX_PRE_WAVES) void prescan_dp_kernel(PreDesc D
     }
 }
 
-// ---- row-split DP kernel (smx_prescan_core.h prescan_dp_rs): one wave per (tile, primer, tile half); lane = (group of the
-// half, end, row half).  MRH = rows per lane: 11 / 12 / 16 for primers of up to 22 / 24 / 31 nt.
-#ifndef SMX_RS_WAVES
-#define SMX_RS_WAVES 3   // waves per SIMD the row-split kernel is compiled for (4 = 128 registers: spills 90-270 bytes per lane)
-#endif
-template <int MRH, int NX, int MT>
-__global__ __launch_bounds__(64, SMX_RS_WAVES) void prescan_dp_rs_kernel(PreDesc D, const unsigned *__restrict__ gplanes,
-                                                              unsigned *__restrict__ out, unsigned *__restrict__ match,
-                                                              uint32_t ntiles) {
-    __shared__ unsigned scratch[PRE_RS_SCRATCH];
-    const int lane = threadIdx.x;
-    const int CH = D.S >> 4;
-    // work item -> (tile, primer, tile half): the 2 NP waves of one tile read the same planes; their workgroup ids are equal
-    // mod 8 (one XCD, one L2) and close together
-    const uint32_t per8 = 16u * (uint32_t)D.NP;
-    const uint32_t nwork = ((ntiles + 7u) >> 3) * per8;
-    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const uint32_t grp = wi / per8, rem = wi - grp * per8;
-        const uint32_t tile = grp * 8u + (rem & 7u);
-        const int q = (int)(rem >> 3), p = q >> 1, th = q & 1;
-        if (tile >= ntiles) continue;
-        const int pairidx = lane >> 1, X = pairidx & 1, g = th * 16 + (pairidx >> 1);
-        prescan_dp_rs<MRH, NX, MT>(gplanes + (size_t)tile * CH * 8 * 64 * 4, scratch, lane, th, CH, D, p,
-                                   out + ((size_t)tile * (2 * D.NP) + (size_t)(2 * p + X)) * CH * PRE_TILE + (uint32_t)g * 32u, PRE_TILE,
-                                   match + ((size_t)tile * (2 * D.NP) + (size_t)(2 * p + X)) * PRE_G + (uint32_t)g);
-    }
-}
-
 }  // namespace smx
 
 extern "C" int smx_prescan_transpose_threads(int S) { (void)S; return smx::PRE_TNT; }
@@ -208,16 +180,8 @@ extern "C" size_t smx_prescan_lds_bytes(int S) {   // the transpose kernel's sta
 #define SMX_PRE_VARIANTS(X) X(22, 0) X(22, 4) X(24, 0) X(24, 4) X(31, 0) X(31, 4)
 static int prescan_rows(int mr) { return mr <= 22 ? 22 : (mr <= 24 ? 24 : 31); }   // DP rows compiled in: inert rows cost as much as live ones
 
-// the row-split kernel's rows per lane for the same three classes
-#define SMX_PRE_RS_VARIANTS(X) X(22, 11, 0) X(22, 11, 4) X(24, 12, 0) X(24, 12, 4) X(31, 16, 0) X(31, 16, 4)
-
-static const void *prescan_fn(int mr, int nx, int rs) {
+static const void *prescan_fn(int mr, int nx) {
     const int mrv = prescan_rows(mr), nxv = nx > 0 ? 4 : 0;
-    if (rs) {
-#define X(MRV, MRH, NXV) if (mrv == MRV && nxv == NXV) return (const void *)smx::prescan_dp_rs_kernel<MRH, NXV, 1>;
-        SMX_PRE_RS_VARIANTS(X)
-#undef X
-    }
 #define X(MRV, NXV) if (mrv == MRV && nxv == NXV) return (const void *)smx::prescan_dp_kernel<MRV, NXV, 1>;
     SMX_PRE_VARIANTS(X)
 #undef X
@@ -229,7 +193,7 @@ static const void *prescan_fn(int mr, int nx, int rs) {
 extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int grid_t, size_t lds_t, int grid_d, void *stream,
                                   const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, int stride,
                                   unsigned *d_planes, unsigned *d_out, unsigned *d_match, void *ev_mid, unsigned *d_codes2,
-                                  uint8_t *d_naflag, int rs) {
+                                  uint8_t *d_naflag) {
     static_assert(smx::PRE_MAXROWS == 31 && smx::PRE_MAXSYM == 8, "variant table");
     const uint32_t ntiles = (n_reads + smx::PRE_TILE - 1) / smx::PRE_TILE;
     const uint32_t nsub = ntiles * (smx::PRE_G / smx::PRE_SUBG);   // every sub-tile of the last tile: the DP kernel reads whole tiles
@@ -240,18 +204,6 @@ extern "C" int smx_launch_prescan(const smx::PreDesc *D, int mr, int nx, int gri
     if (e != hipSuccess) return (int)e;
     if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);   // diagnostic: boundary between the two kernels
     const int mrv = prescan_rows(mr), nxv = nx > 0 ? 4 : 0;
-    if (rs) {
-#define X(MRV, MRH, NXV)                                                                                       \
-    if (mrv == MRV && nxv == NXV) {                                                                            \
-        if (d_match)                                                                                           \
-            hipLaunchKernelGGL((smx::prescan_dp_rs_kernel<MRH, NXV, 1>), dim3(grid_d), dim3(64), 0, s, *D, d_planes, d_out, d_match, ntiles); \
-        else                                                                                                   \
-            hipLaunchKernelGGL((smx::prescan_dp_rs_kernel<MRH, NXV, 0>), dim3(grid_d), dim3(64), 0, s, *D, d_planes, d_out, d_match, ntiles); \
-    }
-        SMX_PRE_RS_VARIANTS(X)
-#undef X
-        return (int)hipGetLastError();
-    }
 #define X(MRV, NXV)                                                                                            \
     if (mrv == MRV && nxv == NXV) {                                                                            \
         if (d_match)                                                                                           \
@@ -268,9 +220,9 @@ extern "C" int smx_prescan_set_lds_limit(size_t bytes) {
     return (int)hipFuncSetAttribute((const void *)smx::prescan_transpose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-extern "C" int smx_prescan_occupancy(int S, int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d, int rs) {
+extern "C" int smx_prescan_occupancy(int S, int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d) {
     (void)S;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_t, (const void *)smx::prescan_transpose_kernel, smx::PRE_TNT, lds_t);
     if (e != hipSuccess) return (int)e;
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_d, prescan_fn(mr, nx, rs), 64, 0);
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_d, prescan_fn(mr, nx), 64, 0);
 }

@@ -274,6 +274,11 @@ SMX_HD void prescan_dp(const unsigned *gpl, unsigned *scratch, int lane, int CH,
         Pv[i] = i >= skip ? ~0u : 0u; Mv[i] = 0u;
         aoff[i] = (i >= skip ? (int)D.sym[p][i - skip] : PRE_MAXSYM) * 64 + lane;
     }
+    // (the compiler merges these four byte reads of the kernel-argument struct into one s_load_dword; its SGPR base must stay
+    // dword aligned -- scalar loads ignore the two low bits of the base -- which holds as long as the base is the kernarg
+    // pointer itself and 8 p + 148 the offset.  A row-split variant of this kernel, round 3, got (kernarg + p) as base -- reused
+    // from the m[p] byte read -- and every primer with p % 4 != 0 silently read another primer's masks: the c3 panel's GPU
+    // tests, whose degenerate primers sit at p = 2, 3, 6, 7, are the guard.)
     unsigned xm[NX > 0 ? NX : 1][4];   // uniform: all-ones where extra symbol 4 + x contains A / C / T / G
 #pragma unroll
     for (int x = 0; x < (NX > 0 ? NX : 1); x++)
@@ -407,254 +412,6 @@ SMX_HD void prescan_dp(const unsigned *gpl, unsigned *scratch, int lane, int CH,
             eq &= ~(nb[b] ^ tb);
         }
         *mout = gt | eq;
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Row-split DP ("RS"): the rows of one (primer, group, end) problem are shared by TWO adjacent lanes -- lane 2k ("upper")
-// owns rows 0 .. MRH-1, lane 2k + 1 ("lower") rows MRH .. 2 MRH - 1 -- so a lane's dependent instruction chain per column
-// is half as long, a lane holds half the DP column in registers (four waves per SIMD instead of two), and a batch offers
-// twice as many waves.  The two halves run one column apart: in step j the lower lane computes column j with the horizontal
-// deltas the upper lane produced for column j in step j - 1 (one DPP lane swap per delta word), while the upper lane is
-// already on column j + 1.  A wave = 16 groups x 2 ends x 2 halves = half a tile for one primer.
-// Eq words: every lane keeps its own double-buffered scratch column (ring U for upper lanes, ring L for lower lanes; the
-// parity of the step selects the buffer, so every LDS address is a register + immediate), written one step ahead from the
-// plane words of the lane's own next column.  No lane reads another lane's scratch: no barriers.
-// Host build (CPU simulation): one call simulates both halves of a pair in lockstep (NH = 2, `lane` = pair index).
-constexpr int PRE_RS_PARW = (PRE_MAXSYM + 1) * 32;   // dwords per (ring, parity) scratch buffer: [symbol][pair]
-// ring L sits 16 dwords further than a multiple of 32: the two lanes of a pair then read different LDS banks (bank = dword
-// mod 32 within a 32-lane half-wave: upper lanes pair, lower lanes pair + 16)
-constexpr int PRE_RS_RINGL = 2 * PRE_RS_PARW + 16;
-constexpr int PRE_RS_SCRATCH = 4 * PRE_RS_PARW + 16;
-
-template <int MRH, int NX, int MT = 1>
-SMX_HD void prescan_dp_rs(const unsigned *gpl, unsigned *scratch, int lane, int th, int CH, const PreDesc &D, int p, unsigned *wout,
-                          size_t cstride, unsigned *mout) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NH = 1;
-    const int pairidx = lane >> 1;
-#else
-    constexpr int NH = 2;
-    const int pairidx = lane;
-#endif
-    const int m = D.m[p], skip = 2 * MRH - m;
-    const int plane_lane = (th * 16 + (pairidx >> 1)) * 2 + (pairidx & 1);   // (group, end) of the tile whose planes this pair reads
-    struct Half {
-        unsigned Pv[MRH], Mv[MRH];
-        int aoff[MRH];
-        unsigned hmask;                      // lower: all ones, upper: 0
-        unsigned Ph_prev, Mh_prev;           // horizontal deltas out of this half's last row, previous step
-        unsigned g0, g1, g2, g3, g4, zero, n0, n1, n2, n3, n4;
-        unsigned fl[32];
-        unsigned eqb[2][8];
-        unsigned *ring;                      // this half's scratch slot: ring base + pair
-    } H[NH];
-    unsigned xm[NX > 0 ? NX : 1][4];   // uniform: all-ones where extra symbol 4 + x contains A / C / T / G
-#pragma unroll
-    for (int x = 0; x < (NX > 0 ? NX : 1); x++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) xm[x][b] = ((D.symmask[p][4 + x] >> b) & 1) ? ~0u : 0u;
-#pragma unroll
-    for (int hh = 0; hh < NH; hh++) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const int half = lane & 1;
-#else
-        const int half = hh;
-#endif
-        Half &h = H[hh];
-        h.hmask = half ? ~0u : 0u;
-        h.ring = scratch + half * PRE_RS_RINGL + pairidx;
-#pragma unroll
-        for (int i = 0; i < MRH; i++) {
-            // rows i (upper) and MRH + i (lower) of the 2 MRH-row problem; the pattern occupies rows skip .. 2 MRH - 1.  Both
-            // candidates come from wave-uniform loads; the lane keeps its half's
-            const bool liveU = i >= skip, liveL = MRH + i >= skip;
-            const int aU = (liveU ? (int)D.sym[p][liveU ? i - skip : 0] : PRE_MAXSYM) * 32;
-            const int aL = (liveL ? (int)D.sym[p][liveL ? MRH + i - skip : 0] : PRE_MAXSYM) * 32;
-            const bool live = half ? liveL : liveU;
-            h.Pv[i] = live ? ~0u : 0u; h.Mv[i] = 0u;
-            h.aoff[i] = half ? aL : aU;
-        }
-        h.g0 = h.g1 = h.g2 = h.g3 = h.g4 = 0u; h.zero = ~0u;
-        h.n0 = h.n1 = h.n2 = h.n3 = h.n4 = 0u;
-        h.Ph_prev = h.Mh_prev = 0u;
-        h.ring[PRE_MAXSYM * 32] = ~0u; h.ring[PRE_RS_PARW + PRE_MAXSYM * 32] = ~0u;   // the inert rows' Eq word, both parities
-    }
-    // plane words of the current and the next four-column group (8 words each), fetched one group ahead; both halves of a
-    // pair fetch the same words (one of them is an L1 hit)
-    unsigned pw[2][8];
-    auto fetch = [&](int grp, unsigned (&dst)[8]) {
-        const int chunk = grp >> 2, q = (grp & 3) * 2;
-#if defined(__HIP_DEVICE_COMPILE__)
-        const uint4 *g4 = (const uint4 *)gpl;
-        const uint4 u0 = g4[((size_t)chunk * 64 + plane_lane) * 8 + q], u1 = g4[((size_t)chunk * 64 + plane_lane) * 8 + q + 1];
-        dst[0] = u0.x; dst[1] = u0.y; dst[2] = u0.z; dst[3] = u0.w; dst[4] = u1.x; dst[5] = u1.y; dst[6] = u1.z; dst[7] = u1.w;
-#else
-        for (int j = 0; j < 8; j++) dst[j] = gpl[prescan_plane_word(chunk, plane_lane, 4 * q + j)];
-#endif
-    };
-    auto occ = [&](unsigned *sc, unsigned b0, unsigned b1) {   // sc = [symbol 0][this pair] of one (ring, parity) buffer
-        const unsigned E0 = ~b0 & ~b1, E1 = b0 & ~b1, E2 = ~b0 & b1, E3 = b0 & b1;   // A, C, T, G
-        sc[0] = E0; sc[32] = E1; sc[64] = E2; sc[96] = E3;
-#pragma unroll
-        for (int x = 0; x < NX; x++)
-            sc[(4 + x) * 32] = (E0 & xm[x][0]) | (E1 & xm[x][1]) | (E2 & xm[x][2]) | (E3 & xm[x][3]);
-    };
-    constexpr int NG = (MRH + 7) / 8;
-    // the cells of one column for one half: rows in groups of eight, the Eq words of the next group (of the next step's first
-    // group after the last one: other parity) requested before this group's cells run
-    auto cells = [&](Half &h, int par, unsigned &Ph, unsigned &Mh) {
-        const unsigned *sc = h.ring + par * PRE_RS_PARW, *scn_other = h.ring + (par ^ 1) * PRE_RS_PARW;
-#pragma unroll
-        for (int gi = 0; gi < NG; gi++) {
-            const int cur = gi & 1;   // (NG = 2: group 0 reads eqb[0], group 1 eqb[1]; the next step's group 0 lands in eqb[0] again)
-            const int gn = gi + 1 < NG ? gi + 1 : 0;
-            const unsigned *scn = gi + 1 < NG ? sc : scn_other;
-#pragma unroll
-            for (int u = 0; u < 8; u++) if (gn * 8 + u < MRH) h.eqb[cur ^ 1][u] = scn[h.aoff[gn * 8 + u]];
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-            for (int u = 0; u < 8; u++) if (gi * 8 + u < MRH) {
-                const int i = gi * 8 + u;
-#if defined(__HIP_DEVICE_COMPILE__)
-                unsigned Z, nPh, nMh;
-                asm volatile("v_bitop3_b32 %[z], %[eq], %[mh], %[mv] bitop3:0xfe\n\t"
-                             "v_bitop3_b32 %[pho], %[mv], %[z], %[pv] bitop3:0xf1\n\t"
-                             "v_and_b32 %[mho], %[pv], %[z]\n\t"
-                             "v_bitop3_b32 %[pv], %[mh], %[z], %[ph] bitop3:0xf1\n\t"
-                             "v_and_b32 %[mv], %[ph], %[z]"
-                             : [z] "=&v"(Z), [pho] "=&v"(nPh), [mho] "=&v"(nMh), [pv] "+v"(h.Pv[i]), [mv] "+v"(h.Mv[i])
-                             : [eq] "v"(h.eqb[cur][u]), [mh] "v"(Mh), [ph] "v"(Ph));
-                Ph = nPh; Mh = nMh;
-#else
-                const unsigned Z = h.eqb[cur][u] | Mh | h.Mv[i];
-                const unsigned nPh = h.Mv[i] | ~(Z | h.Pv[i]);
-                const unsigned nMh = h.Pv[i] & Z;
-                const unsigned nPv = Mh | ~(Z | Ph);
-                const unsigned nMv = Ph & Z;
-                h.Pv[i] = nPv; h.Mv[i] = nMv; Ph = nPh; Mh = nMh;
-#endif
-            }
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-    };
-    static_assert(NG == 2, "Eq prefetch: two row groups per half (9 .. 16 rows)");
-    // ---- start: group 0 of the planes; the upper half's column 0 into ring U, parity 1
-    fetch(0, pw[0]);
-#pragma unroll
-    for (int hh = 0; hh < NH; hh++) {
-        Half &h = H[hh];
-        if (NH == 2 ? hh == 0 : true) occ(h.ring + PRE_RS_PARW, pw[0][0], pw[0][1]);   // (device: the lower lanes write their ring too: harmless)
-    }
-    // ---- step -1: the upper half computes column 0 alone; every half writes the scratch column of its step-0 column
-#pragma unroll
-    for (int hh = 0; hh < NH; hh++) {
-        Half &h = H[hh];
-        // own next column: lower -> column 0, upper -> column 1
-        const unsigned b0 = (pw[0][0] & h.hmask) | (pw[0][2] & ~h.hmask), b1 = (pw[0][1] & h.hmask) | (pw[0][3] & ~h.hmask);
-        occ(h.ring, b0, b1);
-        if (!h.hmask) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) if (u < MRH) h.eqb[0][u] = (h.ring + PRE_RS_PARW)[h.aoff[u]];
-            unsigned Ph = 0u, Mh = 0u;
-            cells(h, 1, Ph, Mh);
-            h.Ph_prev = Ph; h.Mh_prev = Mh;
-        }
-        // first Eq group of step 0 (for the upper half the same words its prefetch has just requested)
-#pragma unroll
-        for (int u = 0; u < 8; u++) if (u < MRH) h.eqb[0][u] = h.ring[h.aoff[u]];
-    }
-    // ---- steps 0 .. 16 CH - 1
-    for (int ch = 0; ch < CH; ch++) {
-#pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int gq = t >> 2, tq = t & 3, cur = gq & 1, par = t & 1;
-            if (tq == 0 && (ch * 4 + gq + 1 < CH * 4)) fetch(ch * 4 + gq + 1, pw[cur ^ 1]);
-            unsigned inPh[NH], inMh[NH];
-#if defined(__HIP_DEVICE_COMPILE__)
-            // the partner's deltas of the previous step: lanes 2k <-> 2k + 1 (DPP quad_perm [1, 0, 3, 2]); the upper half's top row is free
-            inPh[0] = (unsigned)__builtin_amdgcn_mov_dpp((int)H[0].Ph_prev, 0xB1, 0xF, 0xF, true) & H[0].hmask;
-            inMh[0] = (unsigned)__builtin_amdgcn_mov_dpp((int)H[0].Mh_prev, 0xB1, 0xF, 0xF, true) & H[0].hmask;
-#else
-            inPh[0] = 0u; inMh[0] = 0u;
-            inPh[1] = H[0].Ph_prev; inMh[1] = H[0].Mh_prev;
-#endif
-#pragma unroll
-            for (int hh = 0; hh < NH; hh++) {
-                Half &h = H[hh];
-                // scratch column of the NEXT step: lower -> column j + 1, upper -> column j + 2 (j = 16 ch + t)
-                {
-                    const unsigned l0 = tq < 3 ? pw[cur][2 * tq + 2] : pw[cur ^ 1][0], l1 = tq < 3 ? pw[cur][2 * tq + 3] : pw[cur ^ 1][1];
-                    const unsigned u0 = tq < 2 ? pw[cur][2 * tq + 4] : pw[cur ^ 1][2 * tq - 4], u1 = tq < 2 ? pw[cur][2 * tq + 5] : pw[cur ^ 1][2 * tq - 3];
-                    occ(h.ring + (par ^ 1) * PRE_RS_PARW, (l0 & h.hmask) | (u0 & ~h.hmask), (l1 & h.hmask) | (u1 & ~h.hmask));
-                }
-                unsigned Ph = inPh[hh], Mh = inMh[hh];
-                cells(h, par, Ph, Mh);
-                h.Ph_prev = Ph; h.Mh_prev = Mh;
-                // last row (lower half: the pattern's last row): score += Ph - Mh; gap = score - running minimum
-                const unsigned lt = h.zero & Mh;
-                unsigned cy = Ph, bw = Mh ^ lt, tt;
-                tt = h.g0 & cy; h.g0 ^= cy; cy = tt;
-                tt = h.g1 & cy; h.g1 ^= cy; cy = tt;
-                tt = h.g2 & cy; h.g2 ^= cy; cy = tt;
-                tt = h.g3 & cy; h.g3 ^= cy; cy = tt;
-                h.g4 ^= cy;
-                tt = ~h.g0 & bw; h.g0 ^= bw; bw = tt;
-                tt = ~h.g1 & bw; h.g1 ^= bw; bw = tt;
-                tt = ~h.g2 & bw; h.g2 ^= bw; bw = tt;
-                tt = ~h.g3 & bw; h.g3 ^= bw; bw = tt;
-                h.g4 ^= bw;
-                h.zero = ~(h.g0 | h.g1 | h.g2 | h.g3 | h.g4);
-                if (MT) {
-                    cy = lt;
-                    tt = h.n0 & cy; h.n0 ^= cy; cy = tt;
-                    tt = h.n1 & cy; h.n1 ^= cy; cy = tt;
-                    tt = h.n2 & cy; h.n2 ^= cy; cy = tt;
-                    tt = h.n3 & cy; h.n3 ^= cy; cy = tt;
-                    h.n4 ^= cy;
-                }
-                h.fl[t] = lt;
-                h.fl[16 + t] = h.zero;
-            }
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_sched_barrier(0);   // keep the live ranges column-sized
-#endif
-        }
-#pragma unroll
-        for (int hh = 0; hh < NH; hh++) {
-            Half &h = H[hh];
-            transpose32(h.fl);   // -> one word per read: lt flags | e flags << 16 of this chunk (meaningful in the lower half)
-            if (h.hmask) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                uint4 *dst = (uint4 *)(wout + (size_t)ch * cstride);
-#pragma unroll
-                for (int r = 0; r < 8; r++) dst[r] = make_uint4(h.fl[4 * r], h.fl[4 * r + 1], h.fl[4 * r + 2], h.fl[4 * r + 3]);
-#else
-                for (int r = 0; r < 32; r++) wout[(size_t)ch * cstride + r] = h.fl[r];
-#endif
-            }
-        }
-    }
-    if (MT) {
-#pragma unroll
-        for (int hh = 0; hh < NH; hh++) {
-            Half &h = H[hh];
-            const unsigned thr = (unsigned)(m - (int)D.k[p]);
-            const unsigned nb[5] = {h.n0, h.n1, h.n2, h.n3, h.n4};
-            unsigned gt = 0u, eq = ~0u;
-#pragma unroll
-            for (int b = 4; b >= 0; b--) {
-                const unsigned tb = ((thr >> b) & 1u) ? ~0u : 0u;
-                gt |= eq & nb[b] & ~tb;
-                eq &= ~(nb[b] ^ tb);
-            }
-            if (h.hmask) *mout = gt | eq;
-        }
     }
 }
 

@@ -290,6 +290,7 @@ class BatchReplayer:
         self.derep_best = getattr(args, "dereplicate", "best") == "best"
         self.b_len = specimens.b_length()
         self.pf_min = (len(panel.barcodes[0]) - parameters.max_dist_index) if prefilter_on else 0
+        self._collect = None
 
     # ---- find_candidate_matches (demultiplex.py:668-746) + match_one_end (:748-820)
     def _end_events(self, tl, sid, L, seq_str, primer, which, hit, bd):
@@ -325,9 +326,12 @@ class BatchReplayer:
         out.sort(key=lambda x: x[1])   # stable, like the reference's re-sort on every insertion
         return out
 
-    def replay(self, tl: TraceLogger, record, seq_str, sid, hits, bdist, rec_ops):
+    def replay(self, tl: TraceLogger, record, seq_str, sid, hits, bdist, rec_ops, collect=None):
         """Log the events of one read; returns nothing.  hits: smx_hit[2*NP], bdist: int8[2*NP][maxB],
-        rec_ops: the kernel's records for this read in emission order (cross-check)."""
+        rec_ops: the kernel's records for this read in emission order (cross-check; None: no cross-check).
+        collect (list): receives one (candidate, sample_id, ResolutionType, trim_start, trim_end, trim_was_empty) per
+        emitted record -- the host-evaluated prefilter path builds its write operations from these."""
+        self._collect = collect
         L = len(seq_str)
         tl.log_sequence_received(sid, L, record.id)
         a = self.args
@@ -401,7 +405,7 @@ class BatchReplayer:
                 for m in best:
                     fid, rt = self._resolve(tl, sid, m)
                     emitted.append(self._emit(tl, sid, m, fid, rt))
-        got = [(s_, rt_) for s_, rt_ in rec_ops]
+        got = [(s_, rt_) for s_, rt_ in rec_ops] if rec_ops is not None else emitted
         if got != emitted:
             raise RuntimeError(f"trace replay disagrees with the kernel for read {record.id}: kernel {got}, replay {emitted}")
 
@@ -512,13 +516,18 @@ class BatchReplayer:
 
     # ---- create_write_operation's trace side (demultiplex.py:30-103): trim-to-empty fallback, Q8 shift
     def _emit(self, tl, sid, m, sample_id, rt):
+        s, e = 0, m.L
         if self.trim != TrimMode.NONE:
             s, e = m.extent(self.trim, self.b_len)
             if s >= e:
                 tl.log_sequence_trim_empty(sid, self.trim, s, e, m.L, m.p1.name if m.p1 else "unknown",
                                            m.p2.name if m.p2 else "unknown")
+                if getattr(self, "_collect", None) is not None:
+                    self._collect.append((m, SampleId.UNKNOWN, ResolutionType.UNKNOWN, 0, m.L, True))
                 return SampleId.UNKNOWN, ResolutionType.UNKNOWN
             m.cum += s
+        if getattr(self, "_collect", None) is not None:
+            self._collect.append((m, sample_id, rt, s, e, False))
         return sample_id, rt
 
 
@@ -597,3 +606,13 @@ def replay_batch(tl: TraceLogger, replayer: BatchReplayer, seq_records, seqs, op
                 rec_ops.append((sample, rtype))
             replayer.replay(tl, record, seqs[i], sid, hits[i], bdist[i], rec_ops)
     return ids
+
+
+class NullTrace:
+    """A trace logger that logs nothing (verbosity 0): lets BatchReplayer.replay run as a plain scorer."""
+    verbosity = 0
+
+    def __getattr__(self, name):
+        if name.startswith("log_"):
+            return lambda *a, **k: None
+        raise AttributeError(name)

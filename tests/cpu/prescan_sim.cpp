@@ -160,8 +160,7 @@ int main(int argc, char **argv) {
             }
         }
     }
-    std::vector<unsigned> scratch(PRE_SCRATCH), rs_scratch(PRE_RS_SCRATCH);
-    const bool use_rs = getenv("SIM_RS") != nullptr;
+    std::vector<unsigned> scratch(PRE_SCRATCH);
     long checked = 0, matched = 0, multi = 0;
     const int MW = (S + 31) / 32;
     std::vector<unsigned> words((size_t)CH * 32);
@@ -169,12 +168,6 @@ int main(int argc, char **argv) {
         for (int lane = 0; lane < 64; lane++) {   // phase 3: lane = (group, end)
             const int g = lane >> 1, X = lane & 1;
             unsigned mword = 0;
-            if (use_rs) {   // the row-split DP: one call simulates both lanes of the pair (lane = pair index inside its tile half)
-                const int th = lane >> 5, pair = lane & 31;
-                if (D.m[p] <= 22 && (p & 1)) prescan_dp_rs<11, PRE_MAXSYM - 4>(gpl.data(), rs_scratch.data(), pair, th, CH, D, p, words.data(), 32, &mword);
-                else if (D.m[p] <= 24) prescan_dp_rs<12, PRE_MAXSYM - 4>(gpl.data(), rs_scratch.data(), pair, th, CH, D, p, words.data(), 32, &mword);
-                else prescan_dp_rs<16, PRE_MAXSYM - 4>(gpl.data(), rs_scratch.data(), pair, th, CH, D, p, words.data(), 32, &mword);
-            } else
             if (D.m[p] <= 22 && (p & 1)) prescan_dp<22, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32, &mword);   // (both row counts that fit)
             else if (D.m[p] <= 24) prescan_dp<24, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32, &mword);
             else prescan_dp<31, PRE_MAXSYM - 4>(gpl.data(), scratch.data(), lane, CH, D, p, words.data(), 32, &mword);

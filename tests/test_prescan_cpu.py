@@ -19,11 +19,7 @@ def sim(tmp_path_factory):
 
 @pytest.mark.parametrize("args", [("80", "1"), ("160", "2"), ("16", "3"), ("256", "4"), ("80", "7", "one-degenerate-letter"),
                                   ("48", "9")], ids=lambda a: "S%s-seed%s%s" % (a[0], a[1], "-nsym5" if len(a) > 2 else ""))
-@pytest.mark.parametrize("row_split", [False, True], ids=["one-lane-per-problem", "row-split"])
-def test_prescan_equals_dp(sim, args, row_split):
-    """row_split: the DP kernel that shares a problem's rows between two lanes one column apart (prescan_dp_rs), both lanes
-    of a pair simulated in lockstep."""
-    env = dict(os.environ, SIM_RS="1") if row_split else {k: v for k, v in os.environ.items() if k != "SIM_RS"}
-    out = subprocess.run([sim, *args], capture_output=True, text=True, env=env)
+def test_prescan_equals_dp(sim, args):
+    out = subprocess.run([sim, *args], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert " 0 mismatches" in out.stdout

@@ -17,16 +17,19 @@ from .models import WriteOperation, reverse_complement
 from .panel import CompiledPanel
 
 
+def _is_user_prefilter(prefilter) -> bool:
+    """Anything that implements the reference's BarcodePrefilter protocol (databases.py:311-316: `match(barcode,
+    sequence) -> bool`) other than the two built-ins."""
+    return not (prefilter is None or isinstance(prefilter, PassthroughPrefilter) or getattr(prefilter, "smx_exact_set", False))
+
+
 def _prefilter_enabled(prefilter) -> bool:
     """None / PassthroughPrefilter -> off.  A BloomPrefilter (bloom_filter.py) -> the exact-set rule in
-    the kernel.  Arbitrary user prefilters cannot run on the device."""
-    if prefilter is None or isinstance(prefilter, PassthroughPrefilter):
+    the kernel.  Arbitrary user prefilters are Python callables: process_sequences evaluates them on the host
+    (_process_with_user_prefilter); the kernel then runs with its own rule off."""
+    if prefilter is None or isinstance(prefilter, PassthroughPrefilter) or _is_user_prefilter(prefilter):
         return False
-    if getattr(prefilter, "smx_exact_set", False):
-        return True
-    raise NotImplementedError(
-        f"prefilter {type(prefilter).__name__} cannot be evaluated on the GPU; pass None, "
-        "PassthroughPrefilter() or specimux_amd.bloom_filter.BloomPrefilter")
+    return True
 
 
 def compiled_panel(specimens, parameters, args, prefilter, want_starts=False) -> CompiledPanel:
@@ -192,11 +195,130 @@ class _Locator:
         return tuple(None if loc is None else (loc[0] - shift, loc[1] - shift) for loc in out)
 
 
+def _process_with_user_prefilter(seq_records, parameters, specimens, args, prefilter, trace_logger, record_offset):
+    """process_sequences for a user-supplied BarcodePrefilter (reference boundary: databases.py:311-323; the call it
+    guards: demultiplex.py:796).  A Python callable cannot run inside the kernel, so this path splits the work: the kernel
+    (its own prefilter rule off, dump mode) does the primer alignments and the orientation votes for the whole batch; the
+    barcode alignments -- only those (barcode, primer location) pairs the user's `match(b_rc, sequence[start:])` lets
+    through, exactly as match_one_end walks them -- go to the device aligner in two batched launches (alignment.AlignCache);
+    selection, dereplication and specimen resolution are replayed on the host by the same code that checks the kernel's
+    records under -d (trace.BatchReplayer).  A slow path by construction (Python per read): the price of an arbitrary
+    callback, paid only by callers who pass one."""
+    from . import trace as _trace
+    from .alignment import AlignCache, align_seq
+    from .constants import AlignMode
+    if getattr(args, "color", False) and not getattr(args, "output_to_files", False):
+        raise NotImplementedError("--color is not available together with a user-supplied barcode prefilter")
+    if trace_logger is not None and getattr(trace_logger, "verbosity", 1) >= 3:
+        raise NotImplementedError("trace level 3 is not available together with a user-supplied barcode prefilter")
+    panel = compiled_panel(specimens, parameters, args, None, want_starts=True)
+    bases, offsets, seqs = concat_records(seq_records)
+    windows, lens = panel.pack_windows(bases, offsets)
+    ops, extra, counts, hits, bdist = panel.run(windows, lens, want_hits=True)
+    S, kidx = parameters.search_len, int(parameters.max_dist_index)
+    primers = panel.primers
+    # ---- stage 1: all optimal locations of every matched (read, primer, end)
+    ends, stage1 = [], []
+    for i, seq_str in enumerate(seqs):
+        if ops["rtype"][i] == _lib.R_FILTERED:
+            continue
+        L, rs_str = len(seq_str), None
+        for pi, primer in enumerate(primers):
+            for X in (0, 1):
+                if hits[i][pi * 2 + X]["pdist"] < 0:
+                    continue
+                if X == 0 and rs_str is None:
+                    rs_str = reverse_complement(seq_str)
+                q = rs_str if X == 0 else seq_str
+                s0 = L - S
+                t = q[(0 if s0 == -1 else s0):L]
+                if t:
+                    stage1.append((primer.primer_rc, t, int(parameters.max_dist_primers[primer.primer]), AlignMode.INFIX))
+                ends.append((i, pi * 2 + X, q, primer))
+    cache = AlignCache()
+    cache.fill(stage1)
+    # ---- stage 2: the barcode alignments the user's prefilter lets through (match_one_end, demultiplex.py:778-815)
+    plan, stage2 = [], []
+    with cache:
+        for i, h, q, primer in ends:
+            L = len(q)
+            pm = align_seq(primer.primer_rc, q, int(parameters.max_dist_primers[primer.primer]), L - S, L)
+            todo = []
+            if pm.matched():
+                for bi, b in enumerate(primer.barcodes):
+                    b_rc = reverse_complement(b)
+                    for loc in pm.locations():
+                        start = loc[1] + 1
+                        if not prefilter.match(b_rc, q[start:]):
+                            continue
+                        todo.append((bi, b_rc, start))
+                        t = q[(0 if start == -1 else start):L][:len(b_rc) + kidx]
+                        if t:
+                            stage2.append((b_rc, t, kidx, AlignMode.PREFIX))
+            plan.append((i, h, q, todo))
+    cache.fill(stage2)
+    hits2 = hits.copy()
+    bdist2 = np.full(bdist.shape, -1, dtype=np.int8)
+    with cache:
+        for i, h, q, todo in plan:
+            L, tail = len(q), None
+            best = {}   # barcode slot -> (distance, alignment): lowest distance, first location on ties
+            for bi, b_rc, start in todo:
+                bm = align_seq(b_rc, q, kidx, start, L, AlignMode.PREFIX)
+                if bm.matched() and (bi not in best or bm.distance() < best[bi][0]):
+                    best[bi] = (bm.distance(), bm)
+            for bi, (d, bm) in best.items():
+                bdist2[i, h, bi] = d
+                e_last = bm.locations()[-1][1]
+                tail = e_last if tail is None or e_last > tail else tail
+            hits2[i, h]["tail_end"] = -1 if tail is None else tail
+    # ---- selection / dereplication / resolution: the reference's control flow replayed over the tables
+    replayer = _trace.BatchReplayer(panel, parameters, specimens, args, False)
+    tl = trace_logger if trace_logger is not None else _trace.NullTrace()
+    write_ops: List[WriteOperation] = []
+    matched = 0
+    for i, record in enumerate(seq_records):
+        sid = trace_logger.get_sequence_id(record, record_offset + i) if trace_logger is not None else None
+        col = []
+        replayer.replay(tl, record, seqs[i], sid, hits2[i], bdist2[i], None, collect=col)
+        qual = getattr(record, "quality_string", None)
+        if qual is None:
+            ann = getattr(record, "letter_annotations", {}) or {}
+            phred = ann.get("phred_quality")
+            qual = "".join(chr(q + 33) for q in phred) if phred is not None else "I" * len(seqs[i])
+        rc = None
+        full = False
+        for m, sample, rt, a, b, empty, asked in col:
+            full = full or asked in (ResolutionType.FULL_MATCH, ResolutionType.DEREPLICATED_FULL)
+            if m.o:
+                if rc is None:
+                    rc = (reverse_complement(seqs[i]), qual[::-1])
+                s_, q_ = rc
+            else:
+                s_, q_ = seqs[i], qual
+            s_, q_ = s_[a:b], q_[a:b]
+            code = ",".join(str(d) if d >= 0 else "X" for d in (m.p1d, m.b1d(), m.b2d(), m.p2d))
+            write_ops.append(WriteOperation(
+                sample_id=sample, seq_id=record.id, distance_code=code, sequence=s_, quality_sequence=q_,
+                quality_scores=[ord(c) - 33 for c in q_], p1_location=None, p2_location=None, b1_location=None, b2_location=None,
+                primer_pool="unknown" if empty else (m.pool or "unknown"),
+                p1_name="unknown" if (empty or not m.p1) else m.p1.name, p2_name="unknown" if (empty or not m.p2) else m.p2.name,
+                resolution_type=rt, trace_sequence_id=sid))
+        matched += 1 if full else 0
+    return write_ops, len(seq_records), matched
+
+
 def process_sequences(seq_records, parameters, specimens, args, prefilter, trace_logger=None,
                       record_offset: int = 0) -> Tuple[List[WriteOperation], int, int]:
     """Demultiplex one batch of reads on the GPU; see the module docstring.  With a trace_logger the kernel also
     returns the hit tables it scored from and trace.py replays the reference's events from them."""
     seq_records = list(seq_records)
+    if _is_user_prefilter(prefilter):
+        if not callable(getattr(prefilter, "match", None)):
+            raise TypeError(f"prefilter {type(prefilter).__name__} has no match(barcode, sequence) method (databases.py:311-316)")
+        return _process_with_user_prefilter(seq_records, parameters, specimens, args, prefilter,
+                                            trace_logger if (trace_logger is not None and getattr(trace_logger, "enabled", True)) else None,
+                                            record_offset)
     tracing = trace_logger is not None and getattr(trace_logger, "enabled", True)
     coloring = bool(getattr(args, "color", False)) and not getattr(args, "output_to_files", False)
     panel = compiled_panel(specimens, parameters, args, prefilter, want_starts=tracing or coloring)

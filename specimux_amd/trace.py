@@ -329,8 +329,8 @@ class BatchReplayer:
     def replay(self, tl: TraceLogger, record, seq_str, sid, hits, bdist, rec_ops, collect=None):
         """Log the events of one read; returns nothing.  hits: smx_hit[2*NP], bdist: int8[2*NP][maxB],
         rec_ops: the kernel's records for this read in emission order (cross-check; None: no cross-check).
-        collect (list): receives one (candidate, sample_id, ResolutionType, trim_start, trim_end, trim_was_empty) per
-        emitted record -- the host-evaluated prefilter path builds its write operations from these."""
+        collect (list): receives one (candidate, sample_id, ResolutionType, trim_start, trim_end, trim_was_empty,
+        ResolutionType asked for) per emitted record -- the host-evaluated prefilter path builds its write operations from these."""
         self._collect = collect
         L = len(seq_str)
         tl.log_sequence_received(sid, L, record.id)
@@ -523,11 +523,11 @@ class BatchReplayer:
                 tl.log_sequence_trim_empty(sid, self.trim, s, e, m.L, m.p1.name if m.p1 else "unknown",
                                            m.p2.name if m.p2 else "unknown")
                 if getattr(self, "_collect", None) is not None:
-                    self._collect.append((m, SampleId.UNKNOWN, ResolutionType.UNKNOWN, 0, m.L, True))
+                    self._collect.append((m, SampleId.UNKNOWN, ResolutionType.UNKNOWN, 0, m.L, True, rt))
                 return SampleId.UNKNOWN, ResolutionType.UNKNOWN
             m.cum += s
         if getattr(self, "_collect", None) is not None:
-            self._collect.append((m, sample_id, rt, s, e, False))
+            self._collect.append((m, sample_id, rt, s, e, False, rt))
         return sample_id, rt
 
 

@@ -981,3 +981,47 @@ def test_pipeline_packed_lanes_equal_ascii_lanes(lib, c2, tmp_path, monkeypatch)
             exp_tree, total, matched = _oracle_tree(pf, sf, str(fq))
             assert (total, matched) == trees[0][:2]
             assert {k: sorted(v) for k, v in exp_tree.items()} == trees[0][3]
+
+
+# ------------------------------------------------------------------ user-supplied barcode prefilters (databases.py:311-323)
+class _SuffixGatePrefilter:
+    """A BarcodePrefilter a user might write: lets a barcode through only if its last 4 letters occur in the first 24
+    letters of the target (cheap seed test).  Unlike the Bloom filter it rejects true matches now and then, so the records
+    differ from both the prefilter-off and the Bloom run: a real test of the host-evaluated path."""
+
+    def __init__(self):
+        self.calls = 0
+
+    def match(self, barcode: str, sequence: str) -> bool:
+        self.calls += 1
+        return barcode[-4:] in sequence[:24]
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(trim="tails"), dict(trim="primers", dereplicate="none"), dict(disable_preorient=True)],
+                         ids=lambda f: ",".join(f"{k}={v}" for k, v in f.items()) or "default")
+def test_user_prefilter_matches_oracle(lib, c2, c3, flags):
+    """process_sequences with an arbitrary BarcodePrefilter object: primer alignments from the kernel, the barcode
+    alignments the callback lets through from the device aligner, selection replayed on the host -- record for record what
+    the oracle (the reference's loop with the same callback, demultiplex.py:796) produces.  Edge-case reads included."""
+    from specimux_amd import synth
+    from specimux_amd.demultiplex import process_sequences
+    from specimux_amd.io_utils import SeqRecord
+    from oracle import specimux_oracle as O
+    from parity_utils import RT
+    for name, (pan, (pf, sf)) in (("c2", c2), ("c3", c3)):
+        rs = synth.make_reads(pan, 500, 321, windows_only=False, n_frac=0.03, **(dict(insert_mean=900, insert_sd=250) if name == "c3" else {}))
+        reads = reads_from_set(rs, range(500), 80) + ([r for r in _edge_reads(pan) if r[0] != "u_base"] if name == "c2" else [])
+        both = Both(pf, sf, **flags)
+        gate, ogate = _SuffixGatePrefilter(), _SuffixGatePrefilter()
+        recs = [SeqRecord(s, rid, rid, q) for rid, s, q in reads]
+        ops, total, matched = process_sequences(recs, both.parameters, both.specimens, both.args, gate)
+        got = [(op.seq_id, op.sample_id, op.distance_code, op.primer_pool, op.p1_name, op.p2_name,
+                RT[op.resolution_type.value], op.sequence, op.quality_sequence) for op in ops]
+        oops, ototal, omatched = O.process_sequences(reads, both.opar, both.opanel, prefilter=ogate)
+        exp = [(op.seq_id, op.sample_id, op.code, op.pool, op.p1, op.p2, RT[op.rtype], op.sequence, op.quality) for op in oops]
+        assert (total, matched) == (ototal, omatched), name
+        assert got == exp, f"{name} {flags}: first difference {next((g, e) for g, e in zip(got, exp) if g != e)}"
+        assert gate.calls == ogate.calls > 1000
+        # and it is not the Bloom / no-prefilter answer by accident
+        plain, _t, _m = both.product_ops(reads)
+        assert [k[:3] for k in plain] != [k[:3] for k in got]

@@ -577,8 +577,10 @@ inline void owners(const smx_op &op, uint32_t T, uint32_t *primary, uint32_t *po
                                    : (cls == 1 ? 0x40000000u + (uint32_t)(op.rtype == SMX_R_PARTIAL_REV) * 0x10000u + (uint32_t)(uint16_t)op.barcode
                                                : 0x7FFFFFFFu);
     uint32_t h = mix(mix(mix(mix(cls * 7919u, (uint32_t)(uint16_t)op.pool), (uint32_t)(uint16_t)op.p1), (uint32_t)(uint16_t)op.p2), skey);
-    *primary = h % T;
     *pool_level = mix(mix(0xABCDu, (uint32_t)(uint16_t)op.pool), skey) % T;
+    // a full match goes to two files (primer-pair directory and pool level, io_utils.py:256-268): one shard owns both, so the
+    // record is formatted -- reverse-complemented, for half of the reads -- once and copied, not formatted twice by two threads
+    *primary = cls == 0 ? *pool_level : h % T;
 }
 
 // Identity of an output file as one integer: record class, pool, primer pair, sample / partial barcode.

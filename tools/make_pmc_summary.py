@@ -10,6 +10,7 @@ root = sys.argv[1]
 names = {"demux_kernel": "summary.json", "prescan_transpose_kernel": "summary_prescan_transpose.json",
          "prescan_dp_kernel": "summary_prescan_dp.json"}
 READS = int(os.environ.get("PROF_READS", "765000"))
+BYTES_PER_READ = int(os.environ.get("PROF_BYTES_PER_READ", "196"))   # 2 * search_len + 4 + 32: 196 at -l 80, 356 at -l 160
 out = {"root": root, "reads_per_launch": READS, "kernels": {}}
 valu = hbm = 0.0
 ok = True
@@ -33,5 +34,5 @@ for k, f in names.items():
 out["valu_instr_per_step"] = valu if ok else None
 out["valu_instr_by_kernel"] = {k: v["counters_per_launch"].get("SQ_INSTS_VALU") for k, v in out["kernels"].items()}
 out["hbm_bytes_per_step"] = hbm if ok else None
-out["algorithmic_bytes_per_step"] = READS * 196   # (196 B/read is the S = 80 figure; -l 160 panels: 356)
+out["algorithmic_bytes_per_step"] = READS * BYTES_PER_READ
 print(json.dumps(out, indent=1))

@@ -8,6 +8,7 @@ OUT=gpurun_out/prof_$TAG
 BENCH="python3 bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 ${BENCH_ARGS:-}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
+case "${BENCH_ARGS:-}" in *c5*) export PROF_BYTES_PER_READ=356;; esac   # -l 160: 2 * 160 + 4 + 32 algorithmic bytes per read
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/kt.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $BENCH > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $BENCH > "$OUT/write.log" 2>&1

@@ -15,6 +15,7 @@ KERNEL = sys.argv[2] if len(sys.argv) > 2 else "demux_kernel"   # kernel name su
 
 STEP_KERNEL = "prescan_transpose_kernel"   # launched exactly once per step: its dispatch count = the number of steps
 READS = int(os.environ.get("PROF_READS", "765000"))
+BYTES_PER_READ = int(os.environ.get("PROF_BYTES_PER_READ", "196"))   # 2 * search_len + 4 + 32: 196 at -l 80, 356 at -l 160
 
 
 def pmc(sub):
@@ -61,5 +62,5 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     fetch_b = counters["FETCH_SIZE"] * 1024 * 2      # gfx950: counter reads half of a 16 B/lane stream
     write_b = counters["WRITE_SIZE"] * 1024
     out["hbm"] = {"fetch_bytes_corrected": fetch_b, "write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b,
-                  "reads_per_launch": READS, "algorithmic_bytes_per_launch": READS * 196}
+                  "reads_per_launch": READS, "algorithmic_bytes_per_launch": READS * BYTES_PER_READ}
 print(json.dumps(out, indent=1))

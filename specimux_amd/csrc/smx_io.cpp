@@ -59,7 +59,10 @@ int io_threads() {
                 }
                 fclose(f);
             }
-            v = std::min(v, 16);   // reader, packer and writer overlap: more threads than this only add contention
+            // reader, packer and writer overlap and spend part of their time in page-cache system calls: half as many threads
+            // again as CPUs keeps the cores busy (measured on the 16-core GPU box, 765k reads file -> tree: 16 threads 0.218 s,
+            // 20 0.202 s, 24 0.177 s), more only add contention
+            v = std::min(v + v / 2, 24);
         }
         return std::max(v, 1);
     }();

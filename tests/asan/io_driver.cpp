@@ -49,6 +49,16 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> win((size_t)n * stride);
         std::vector<int32_t> lens(n);
         if (smx_pack_windows_batch(b, S, win.data(), lens.data()) != 0) die("pack");
+        {   // the 4-bit packer: buffers sized exactly (stride = round16(2 * ceil(S / 2))), several window lengths
+            for (int S4 : {S, 81, 7, 1}) {
+                const size_t ps = ((size_t)(2 * ((S4 + 1) / 2)) + 15) & ~(size_t)15;
+                std::vector<uint8_t> packed((size_t)n * ps);
+                std::vector<int32_t> l4(n);
+                uint32_t n_ascii = 0;
+                if (smx_pack_windows4_batch(b, S4, packed.data(), l4.data(), &n_ascii) != 0) die("pack4");
+                for (uint32_t i = 0; i < n; i++) if (l4[i] != lens[i]) die("pack4 lens");
+            }
+        }
         std::vector<smx_op> ops(n), extra;
         for (uint32_t i = 0; i < n; i++) {
             const char *id, *seq, *qual;

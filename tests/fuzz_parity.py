@@ -29,10 +29,8 @@ def main():
     ap.add_argument("--panel", default=None, choices=["c1", "c2", "c3"], help="this panel only (default: all three in rotation)")
     a = ap.parse_args()
     from specimux_amd import synth
-    flag_sets = [dict(), dict(trim="tails"), dict(trim="primers"), dict(dereplicate="none"), dict(disable_prefilter=True),
-                 dict(disable_preorient=True), dict(search_len=64), dict(search_len=120), dict(index_edit_distance=2),
-                 dict(primer_edit_distance=4), dict(index_edit_distance=4, disable_prefilter=True),
-                 dict(search_len=160, error_rate=0.12, n_frac=0.05), dict(search_len=48, n_frac=0.1), dict(search_len=96, trim="tails")]
+    from parity_utils import FUZZ_FLAG_SETS
+    flag_sets = [dict(f) for f in FUZZ_FLAG_SETS]
     if a.trim:
         flag_sets = [dict(f, trim=a.trim) for f in flag_sets if "trim" not in f]
     if a.index_k is not None:

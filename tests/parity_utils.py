@@ -9,6 +9,13 @@ from oracle import specimux_oracle as O
 
 RT = {1: "FULL", 2: "PFWD", 3: "PREV", 4: "MULTI", 5: "UNKNOWN", 6: "DEREP"}
 
+# flag sets of the randomised parity loops (tests/fuzz_parity.py, test_gpu_parity.py::test_bounded_fuzz); error_rate / n_frac
+# are knobs of the read generator, not specimux flags
+FUZZ_FLAG_SETS = [dict(), dict(trim="tails"), dict(trim="primers"), dict(dereplicate="none"), dict(disable_prefilter=True),
+                  dict(disable_preorient=True), dict(search_len=64), dict(search_len=120), dict(index_edit_distance=2),
+                  dict(primer_edit_distance=4), dict(index_edit_distance=4, disable_prefilter=True),
+                  dict(search_len=160, error_rate=0.12, n_frac=0.05), dict(search_len=48, n_frac=0.1), dict(search_len=96, trim="tails")]
+
 
 def make_args(**kw):
     a = argparse.Namespace(index_edit_distance=-1, primer_edit_distance=-1, search_len=80, disable_preorient=False,

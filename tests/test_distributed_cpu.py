@@ -187,3 +187,47 @@ def test_parallel_merge_equals_rank_order_concatenation(tmp_path):
     assert got == expect
     assert sum(built) == len(expect) and min(built) > 0
     assert not any(p.name.startswith(".smx_rank_") for p in out.iterdir())
+
+
+def _failing_worker(rank, world, port, tmp, seqfile):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SMX_DIST_BACKEND="gloo")
+    from specimux_amd.distributed import run_sharded
+
+    def shard_runner(path, out_dir, byte_range, stride):
+        if rank == 1:
+            raise ValueError("rank 1 cannot read its shard")
+        with open(os.path.join(out_dir, "x.fastq"), "w") as fh:
+            fh.write("@r\nA\n+\nI\n")
+        return 1, 0, np.zeros(9, dtype=np.uint64)
+
+    try:
+        run_sharded(seqfile, os.path.join(tmp, "out"), "", 9, shard_runner)
+        outcome = "returned"
+    except ValueError as e:
+        outcome = f"ValueError: {e}"
+    except RuntimeError as e:
+        outcome = f"RuntimeError: {e}"
+    with open(os.path.join(tmp, f"outcome_{rank}.txt"), "w") as fh:
+        fh.write(outcome)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_failure_is_raised_on_every_rank(tmp_path):
+    """An exception in one rank's shard must not leave the other rank waiting in the counts all-reduce: the ranks agree on a
+    status word first, the failing rank re-raises its exception, the other raises too, no tree is merged, and a stale rank
+    tree left by an earlier (killed) run is gone."""
+    from specimux_amd.distributed import rank_dir
+    seqfile = tmp_path / "reads.fastq"
+    seqfile.write_text("@a\nACGT\n+\nIIII\n" * 50)
+    stale = rank_dir(os.fspath(tmp_path / "out"), 5)
+    os.makedirs(stale)
+    open(os.path.join(stale, "old.fastq"), "w").write("@old\nA\n+\nI\n")
+    port = 29500 + ((os.getpid() + 13) % 2000)
+    mp.spawn(_failing_worker, args=(2, port, os.fspath(tmp_path), os.fspath(seqfile)), nprocs=2, join=True)
+    o0, o1 = (tmp_path / "outcome_0.txt").read_text(), (tmp_path / "outcome_1.txt").read_text()
+    assert o1 == "ValueError: rank 1 cannot read its shard"
+    assert o0.startswith("RuntimeError: another rank failed")
+    assert not os.path.exists(stale)
+    assert not (tmp_path / "out" / "x.fastq").exists()

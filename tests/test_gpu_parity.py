@@ -761,10 +761,7 @@ def test_compact_tiles_other_scan_variants(lib, tmp_path_factory, monkeypatch, s
 
 
 # ------------------------------------------------------------------ randomised evidence inside the suite
-FUZZ_FLAG_SETS = [dict(), dict(trim="tails"), dict(trim="primers"), dict(dereplicate="none"), dict(disable_prefilter=True),
-                  dict(disable_preorient=True), dict(search_len=64), dict(search_len=120), dict(index_edit_distance=2),
-                  dict(primer_edit_distance=4), dict(index_edit_distance=4, disable_prefilter=True),
-                  dict(search_len=160, error_rate=0.12, n_frac=0.05), dict(search_len=48, n_frac=0.1), dict(search_len=96, trim="tails")]
+from parity_utils import FUZZ_FLAG_SETS  # noqa: E402  (shared with the manual loop, tests/fuzz_parity.py)
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])

@@ -1087,72 +1087,77 @@ __device__ inline void score_general(Emitter &E, int ori) {
 // tie-mask word).  The kernel holds > 100 uniform
 // values and spills hundreds of SGPRs; every dimension that is a constant is one fewer of them, and the loops over mask
 // words / distance levels / window chunks get constant trip counts.
-template <typename PW, int NT, int BSV, int CM = 0, int SP = 0>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
-__global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
-                                                    const int32_t *__restrict__ lens, uint32_t n_reads, int R_arg,
-                                                    smx_op *__restrict__ ops, smx_op *__restrict__ extra,
-                                                    uint32_t extra_cap, uint32_t *n_extra,
-                                                    unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist_arg,
-                                                    unsigned *tile_counter, int use_slots_arg,
-                                                    const unsigned *__restrict__ pre, uint32_t npad, DemuxAux aux) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const DevPanel *P = &Pv;
-    constexpr bool sp = SP != 0;
-    // SP = 3: SP = 1 with search_len 160 and 32-read tiles (the wide-window stress shape of a many-primer panel)
-    const int R = SP == 3 ? 32 : (sp ? 64 : R_arg);   // (the specialised kernels are only launched with these tile sizes)
-    // SP = 2: SP = 1 for a panel with two primers (one forward, one reverse: a single amplicon) -- the tile's 256
-    // alignments are one per lane, every LDS offset in front of the panel tables is a constant
-    const int NP = SP == 2 ? 2 : P->NP, NB = P->NB, S = SP == 3 ? 160 : (sp ? 80 : P->S), H = 2 * NP, MW = (S + 31) / 32, maxB = P->maxB;
-    const int need_starts = sp ? 0 : P->need_starts;
-    const int n_pbc = P->n_pbc, NPAIR = SP == 2 ? 1 : P->NPAIR;
-    const int npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
-    // (the default-flags kernels are lean bit-sliced launches by construction: no slots-mode state in them)
-    const int use_slots = SP != 0 ? 0 : use_slots_arg;
-    int8_t *const dbg_bdist = SP != 0 ? nullptr : dbg_bdist_arg;
-    const int use_bs = SP != 0 ? 1 : ((BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0);
-    const int ncand = 2 * NPAIR;
-    const TileLayout T = make_layout<PW>(NP, NB, S, R, maxB, need_starts, npmeta, sp ? 3 : P->kidx, use_slots, P->bs_ok, ncand,
-                                         sp ? 0 : P->cap_hits, sp ? 0 : P->cap_ents, (sp && CM == 1) ? 256 : aux.nitems);
+// The kernel's state and its phases.  One object per thread, every member function inlined: after inlining the members are
+// plain registers / uniform values, exactly as the locals of the former single 970-line function were -- but each phase can be
+// read (and a variant reasoned about) on its own: setup -> stage_panel (phase 0) -> run: per tile phase2_primers ->
+// phase3a_entries -> phase3_rounds (phase3b_barcodes, phase3c_summary) -> zero_for_next -> phase4_score || phase1_encode ->
+// phase5_store.
+template <typename PW, int NT, int BSV, int CM, int SP>
+struct DemuxTile {
+    static constexpr bool sp = SP != 0;
     // compact mode (aux.nitems > 0, lean launches of many-primer panels behind the prescan): records only for the
     // alignments the prescan's match words flag; a tile with more flagged alignments than records is put on the
     // overflow list and left to the dense redo launch that follows (aux.redo)
-    constexpr bool cmode = CM == 1;
-    constexpr bool redo = CM == 2;
-    PW *ppeq = (PW *)(lds + T.ppeq);        // [code][primer], stride NPs
-    PW *prpeq = (PW *)(lds + T.prpeq);
-    unsigned *bpeq = (unsigned *)(lds + T.bpeq);   // [code][barcode], stride NBs
-    unsigned *bsre = (unsigned *)(lds + T.bsre);   // bit-sliced table [primer][row][code][word] (lean mode)
-    unsigned char *lut = lds + T.lut;
-    unsigned char *codes = lds + T.codes;
-    unsigned *namask = (unsigned *)(lds + T.namask);
-    int *lensL = (int *)(lds + T.lens);
-    int *ocnt = (int *)(lds + T.ocnt);
-    int *rflag = (int *)(lds + T.rflag);
-    HitL *hits = (HitL *)(lds + T.hits);
-    unsigned *masks = (unsigned *)(lds + T.masks);
-    unsigned *tiem = (unsigned *)(lds + T.tiem);
-    unsigned *bres = (unsigned *)(lds + T.bres);
-    unsigned *dmask = (unsigned *)(lds + T.dmask);   // lean mode: [hit in round][distance][MBW] barcode bitmasks
-    EntL *ents = (EntL *)(lds + T.ents);
-    int *etail = (int *)(lds + T.etail);     // BSV == 3 only
-    int *offsA = (int *)(lds + T.offsA);    // exclusive scan of searched locations per hit
-    int *offsB = (int *)(lds + T.offsB);    // exclusive scan of searched hits (rank)
-    unsigned short *queue = (unsigned short *)(lds + T.queue);   // rank -> hit
-    int *cumL = (int *)(lds + T.emit);      // scorer: [read][candidate] accumulated trim shift
-    smx_op *opsL = (smx_op *)(lds + T.opsL);
-    int *aggr = (int *)(lds + T.aggr);      // [0..7] counters, [8] round end rank, [9] next tile, [10] fallback items, [11] flagged alignments
-    unsigned short *hmap = (unsigned short *)(lds + T.hmap);     // compact mode: read * H + alignment -> record (T.NI = "no match")
-    unsigned short *clist = (unsigned short *)(lds + T.clist);   // compact mode: record -> read * H + alignment
-    unsigned long long *pmask = (unsigned long long *)(lds + T.pmask);   // per read: alignments with a primer match
-    unsigned long long *hcand = (unsigned long long *)(lds + T.hcand);   // per alignment: its candidates
-    const bool cfilt = H <= 64 && NPAIR * 2 <= 64 && NPAIR * 2 > 4;   // the scorer looks at matched alignments' candidates only
-    int tid = threadIdx.x;
-    const int wave = tid >> 6;
+    static constexpr bool cmode = CM == 1;
+    static constexpr bool redo = CM == 2;
+    static constexpr int PWBITS = (int)sizeof(PW) * 8;
+    // ---- kernel arguments
+    unsigned char *lds;
+    const DevPanel *P;
+    const uint8_t *windows;
+    const int32_t *lens;
+    uint32_t n_reads;
+    smx_op *ops, *extra;
+    uint32_t extra_cap;
+    uint32_t *n_extra;
+    unsigned long long *counts;
+    smx_hit *dbg_hits;
+    int8_t *dbg_bdist;
+    unsigned *tile_counter;
+    const unsigned *pre;
+    DemuxAux aux;
+    // ---- launch-wide facts (compile-time constants in the default-flags kernels)
+    int R, NP, NB, S, H, MW, maxB, need_starts, n_pbc, NPAIR, npmeta, use_slots, use_bs, ncand;
+    TileLayout T;
+    int CS, NPs, NBs, lNPs, lNBs, G, logG, MBW;
+    int stride, kidx, pfmin, preorient, minlen, maxlen, lH, SW;
+    unsigned Hmagic, hcmagic;
+    uint32_t redo_ratio, n_tiles;
+    bool cfilt, timing;
+    unsigned long long *tacc, *dbg_phase;
+    // ---- LDS regions (layout: make_layout)
+    PW *ppeq, *prpeq;
+    unsigned *bpeq, *bsre;
+    unsigned char *lut, *codes;
+    unsigned *namask;
+    int *lensL, *ocnt, *rflag;
+    HitL *hits;
+    unsigned *masks, *tiem, *bres, *dmask;
+    EntL *ents;
+    int *etail, *offsA, *offsB;
+    unsigned short *queue;
+    int *cumL;
+    smx_op *opsL;
+    int *aggr;
+    unsigned short *hmap, *clist;
+    unsigned long long *pmask, *hcand;
+    LPanel LP;
+    // ---- per thread / per tile
+    int tid, wave;
+    uint32_t cur, r0, nxt;      // tile being processed, its first read, the tile being encoded beside its scorer
+    int par, nr, nh, nI;        // cur's lens/ocnt buffer; reads, alignments, alignments with a record
+    bool live;                  // false: nothing to do for `cur` (none yet, or a compact tile left to the redo launch)
+    unsigned popped;
+    int *lensC, *ocntC;
+    const int *rflagC;
+    bool prelisted;
+    int nq, nE_pre;
+
     // The launch counters re-arm themselves: tile_counter = {tile queue head, overflow tiles, finished workgroups, extra
     // records}.  The last workgroup to get here zeroes the queue head; the last launch of a batch (aux.chain == 0) also
     // publishes the extra-record count and zeroes the rest, so a launch needs no memset in front of it (two small fills
     // per batch were ~2 % of a 0.4 ms launch).
-    auto workgroup_done = [&]() {
+    __device__ __forceinline__ void workgroup_done() {
         __threadfence();
         const unsigned prev = atomicAdd(tile_counter + 2, 1u);
         if (prev == gridDim.x - 1) {
@@ -1163,81 +1168,14 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 tile_counter[1] = 0; tile_counter[3] = 0;
             }
         }
-    };
-    if (redo && tile_counter[1] == 0) {   // the usual redo launch: nothing on the list (every workgroup sees the same count:
-        if (tid == 0) workgroup_done();       // it is only zeroed once all of them have passed this point)
-        return;
     }
-    constexpr int PWBITS = (int)sizeof(PW) * 8;
-    const int CS = T.CS, NPs = T.NPs, NBs = T.NBs, lNPs = T.lNPs, lNBs = T.lNBs, G = T.G, logG = T.logG, MBW = sp ? 1 : T.MBW;
-
-    // ---- phase 0: stage the panel (transposed: consecutive lanes = consecutive patterns hit distinct banks)
-    for (int i = tid; i < NP * 16; i += NT) {
-        int p = i >> 4, c = i & 15;
-        ppeq[c * NPs + p] = (PW)P->ppeq[i] << (PWBITS - P->pm[p]);   // left-aligned: row m-1 is the top bit
-        if (need_starts) prpeq[c * NPs + p] = (PW)P->prpeq[i];
-    }
-    if (!use_bs)
-        for (int i = tid; i < NB * 16; i += NT) bpeq[(i & 15) * NBs + (i >> 4)] = P->bpeq[i];
-    if (use_bs)
-        for (int i = tid; i < NP * T.MBW * 256; i += NT) {
-            int blk = i >> 8;   // (primer, word) block: [row][code], the row stride is a compile-time 16 words
-            bsre[blk * T.BSP + (i & 255)] = P->bs_re[i];
-        }
-    for (int i = tid; i < 512; i += NT) lut[i] = P->lut[i];
-    int *pmeta = (int *)(lds + T.pmeta);
-    LPanel LP;
-    {
-        int *q = pmeta;
-        LP.pm = q; q += NP; LP.pk = q; q += NP; LP.pdir = q; q += NP; LP.pfidx = q; q += NP;
-        LP.pbc_off = q; q += NP + 1; LP.pbc = q; q += n_pbc; LP.bm = q; q += NB;
-        LP.pair_f = q; q += NPAIR; LP.pair_r = q; q += NPAIR; LP.pair_pool = q;
-        for (int i = tid; i < NP; i += NT) {
-            pmeta[i] = P->pm[i]; pmeta[NP + i] = P->pk[i]; pmeta[2 * NP + i] = P->pdir[i]; pmeta[3 * NP + i] = P->pfidx[i];
-        }
-        for (int i = tid; i <= NP; i += NT) pmeta[4 * NP + i] = P->pbc_off[i];
-        for (int i = tid; i < n_pbc; i += NT) pmeta[5 * NP + 1 + i] = P->pbc[i];
-        for (int i = tid; i < NB; i += NT) pmeta[5 * NP + 1 + n_pbc + i] = P->bm[i];
-        for (int i = tid; i < NPAIR; i += NT) {
-            int *b = pmeta + 5 * NP + 1 + n_pbc + NB;
-            b[i] = P->pair_f[i]; b[NPAIR + i] = P->pair_r[i]; b[2 * NPAIR + i] = P->pair_pool[i];
-        }
-    }
-    if (tid < 12) aggr[tid] = 0;
-    for (int i = tid; i < R; i += NT) pmask[i] = 0ull;
-    if (cfilt) for (int i = tid; i < H; i += NT) hcand[i] = 0ull;
-    if (cmode && tid == 0) {   // the shared record of every alignment that is not flagged: what the primer scan writes for "no match"
-        HitL hn;
-        hn.tail_end = -1; hn.nloc = 0; hn.ntied = 0; hn.first_tied = -1; hn.pdist = -1; hn.bbest = -2; hn.jstar = 0; hn.fs_j = 0;
-        hn.flags = 0; hn.pad = 0;
-        hits[T.NI] = hn;
-        for (int w = 0; w < T.MBW; w++) tiem[T.NI * T.MBW + w] = 0;
-    }
-    __syncthreads();
-    if (cfilt)
-        for (int ci = tid; ci < NPAIR * 2; ci += NT) {   // candidate ci = (pair, orientation): its two alignments (cand_view)
-            const int pair = ci >> 1, o = ci & 1;
-            const int h1 = LP.pair_f[pair] * 2 + (o == 0 ? 0 : 1), h2 = LP.pair_r[pair] * 2 + (o == 0 ? 1 : 0);
-            atomicOr(&hcand[h1], 1ull << ci);
-            atomicOr(&hcand[h2], 1ull << ci);
-        }
-    __syncthreads();
-
-    const int stride = SP == 3 ? 320 : (sp ? 160 : P->wstride);
-    const int kidx = sp ? 3 : P->kidx, pfmin = P->pfmin;
-    const int preorient = sp ? 1 : P->preorient, minlen = sp ? -1 : P->minlen, maxlen = sp ? -1 : P->maxlen;
     // Integer division by the (uniform, runtime) item strides: a generic `x / H` is a ~30-instruction sequence on the
     // VALU and sits in every per-item loop.  H is a power of two for 1, 2, 4, 8 ... primers (shift); otherwise one
     // v_mul_hi with ceil(2^32 / H), exact for x < 2^32 / H (items are < 2^16).
-    const int lH = (H & (H - 1)) == 0 ? 31 - __clz(H) : -1;
-    const unsigned Hmagic = (unsigned)((0x100000000ull + (unsigned)H - 1) / (unsigned)H);
-    auto divH = [&](int x) -> int { return lH >= 0 ? (x >> lH) : (int)__umulhi((unsigned)x, Hmagic); };
-    const unsigned hcmagic = (unsigned)((0x100000000ull + (unsigned)(S >> 4) - 1) / (unsigned)((S >> 4) > 0 ? (S >> 4) : 1));   // chunk / (S/16)
+    __device__ __forceinline__ int divH(int x) const { return lH >= 0 ? (x >> lH) : (int)__umulhi((unsigned)x, Hmagic); }
     // tile -> reads.  Normal launch: tile t = reads [t R, t R + R).  Redo launch: the overflow list holds tiles of Rc reads
     // each; every one of them is cut into ceil(Rc / R) tiles of this launch.
-    const uint32_t redo_ratio = redo ? (uint32_t)((aux.Rc + R - 1) / R) : 1u;
-    const uint32_t n_tiles = redo ? tile_counter[1] * redo_ratio : (n_reads + R - 1) / R;
-    auto tile_span = [&](uint32_t t, uint32_t &first, int &count) {
+    __device__ __forceinline__ void tile_span(uint32_t t, uint32_t &first, int &count) const {
         if (!redo) {
             first = t * (uint32_t)R;
             count = (int)((n_reads - first) < (uint32_t)R ? (n_reads - first) : (uint32_t)R);
@@ -1249,188 +1187,291 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             count = first < end ? (int)((end - first) < (uint32_t)R ? (end - first) : (uint32_t)R) : 0;
             if (count == 0) first = base;   // keep addresses formed from it in range
         }
-    };
-    // diagnostic phase timing (SMX_PHASE_TIMING=1): thread 0 accumulates s_memtime deltas per phase, in LDS so that
-    // the accumulators cost no registers in the production path
-    unsigned long long *tacc = (unsigned long long *)(lds + T.tacc);   // [0..9] sums, [10] previous stamp
-    // (the default-flags kernels carry no phase timing: SMX_PHASE_TIMING runs use the generic instantiation)
-    unsigned long long *const dbg_phase = sp ? nullptr : P->dbg_phase;
-    const bool timing = dbg_phase != nullptr && tid == 0;
-    if (timing) for (int i = 0; i < 11; i++) tacc[i] = 0;
-// STAMP marks a phase boundary: optional timing, and tid is laundered so that per-thread values are recomputed by
-// the phase that needs them instead of being computed early and carried (spilled) across the register-hungry scans
-#define STAMP(i) do { asm volatile("" : "+v"(tid)); if (timing) { unsigned long long _t = clock64(); tacc[i] += _t - tacc[10]; tacc[10] = _t; } } while (0)
-    // dynamic tile queue: workgroups pull tiles from a global counter (zeroed on the stream before the
-    // launch), so the tail is one tile long whatever the residency turns out to be
-    // Software pipeline over tiles: while the lowest wave(s) run the scorer of tile t (one lane per read), the other
-    // waves load and encode tile t+1.  codes / namask are dead by then; lens and the orientation votes are double-buffered.
-    const int SW = (R + 63) >> 6;              // scorer waves
-    uint32_t cur = 0xFFFFFFFFu;                // tile being processed (none yet)
-    int par = 1;                               // cur's lens/ocnt buffer; the tile being encoded uses par ^ 1
-    for (;;) {
-        // keep per-thread address arithmetic inside the tile body: hoisted out of this loop it lives in VGPRs across
-        // every phase and ends up spilled to scratch (HBM traffic, reload latency); recomputing it is a few ALU ops
+    }
+    // A phase boundary: optional timing (SMX_PHASE_TIMING=1: thread 0 accumulates s_memtime deltas per phase, in LDS so that
+    // the accumulators cost no registers in the production path), and tid is laundered so that per-thread values are
+    // recomputed by the phase that needs them instead of being computed early and carried (spilled) across the
+    // register-hungry scans
+    __device__ __forceinline__ void stamp(int i) {
         asm volatile("" : "+v"(tid));
-        const bool have = cur != 0xFFFFFFFFu;
-        // the tile to encode during this iteration: the queue pop is issued here, its result is only parked in LDS after
-        // the barcode phases (a returning global atomic takes microseconds; storing it at once stalled wave 0, and with
-        // it the first barrier of every tile)
-        unsigned popped = 0;
-        if (tid == 0) popped = atomicAdd(tile_counter, 1u);
-        uint32_t r0 = 0u;
-        int nr = 0;
-        if (have) tile_span(cur, r0, nr);
-        const int nh = nr * H;
-        int nI = nh;          // alignments with a record: all of them, or (compact mode) the flagged ones
-        bool live = have;     // false: nothing to do for `cur` (none yet, or a compact tile left to the redo launch)
-        int *lensC = lensL + par * R, *ocntC = ocnt + par * R;
-        const int *rflagC = rflag + par * R;
-        if (timing) tacc[10] = clock64();
-        if (have) {
-        // ---- phase 2: primer scan, one lane per (read, primer, end).  With the prescan (pre != nullptr) every alignment
-        // it covers is decoded from its flag words; the others (windows with anything but upper-case ACGT) are queued
-        // and scanned afterwards, packed into the lowest lanes, so that one such read does not make its whole wave run
-        // the 80-column scalar scan.
-        unsigned short *fbq = queue;   // fallback items (the rank -> hit queue is not live before phase 3a)
-        auto primer_item = [&](int item, const bool use_pre) {   // item = record index
-            const int dn = cmode ? (int)clist[item] : item;
-            int r = divH(dn), h = dn - __mul24(r, H), p = h >> 1, X = h & 1;
-            int L = lensC[r];
-            EndGeom g = end_geom(L, S);
-            const unsigned char *cw = codes + __mul24(r * 2 + X, CS);
-            const PW *peq = ppeq + p;
-            const int m = LP.pm[p], k = LP.pk[p], top = PWBITS - 1;
-            PW Pvv = ~(PW)0, Mv = 0;
-            int score = m, best = m + 1, jstar = 0, cnt = 0;
-            unsigned *mrow = masks + __mul24(item, MW);
-            // With the prescan: its flag words cover the window's first Sp columns = the whole stored window, which is the
-            // primer target unless the read is shorter than search_len AND its target starts inside the window
-            // (g.j_lo > 0): then only the orientation vote comes from the prescan (determine_orientation looks
-            // at the whole string) and the target [j_lo, Sp) -- at most search_len / 2 columns -- is scanned below.
-            bool pre_done = false, pre_omatch = false;
-            if (use_pre) {
-                const uint32_t gr = r0 + (uint32_t)r;   // flag words: [tile of 1024 reads][alignment h][chunk][read in tile]
-                const unsigned *pw = pre + ((size_t)(gr >> 10) * H + h) * (S >> 4) * PRE_TILE + (gr & (PRE_TILE - 1));
-                const int bfull = S == 160 ? prescan_decode<10>(pw, PRE_TILE, 10, MW, m, k, g.Sp, mrow, &jstar, &cnt)
-                                : S == 80 ? prescan_decode<5>(pw, PRE_TILE, 5, MW, m, k, g.Sp, mrow, &jstar, &cnt)   // the default -l
-                                          : prescan_decode<0>(pw, PRE_TILE, S >> 4, MW, m, k, g.Sp, mrow, &jstar, &cnt);
-                pre_omatch = bfull <= k;
-                if (g.j_lo == 0) { pre_done = true; best = pre_omatch ? bfull : m + 1; }
-                else { jstar = 0; cnt = 0; }
+        if (timing) { unsigned long long _t = clock64(); tacc[i] += _t - tacc[10]; tacc[10] = _t; }
+    }
+
+    // Everything that does not change during the launch.  Returns false when this workgroup has nothing to do at all (the
+    // usual redo launch: an empty overflow list).
+    __device__ __forceinline__ bool setup(unsigned char *lds_, const DevPanel *P_, const uint8_t *windows_, const int32_t *lens_,
+                                          uint32_t n_reads_, int R_arg, smx_op *ops_, smx_op *extra_, uint32_t extra_cap_,
+                                          uint32_t *n_extra_, unsigned long long *counts_, smx_hit *dbg_hits_, int8_t *dbg_bdist_arg,
+                                          unsigned *tile_counter_, int use_slots_arg, const unsigned *pre_, const DemuxAux &aux_) {
+        lds = lds_; P = P_; windows = windows_; lens = lens_; n_reads = n_reads_; ops = ops_; extra = extra_; extra_cap = extra_cap_;
+        n_extra = n_extra_; counts = counts_; dbg_hits = dbg_hits_; tile_counter = tile_counter_; pre = pre_; aux = aux_;
+        // SP = 3: SP = 1 with search_len 160 and 32-read tiles (the wide-window stress shape of a many-primer panel)
+        R = SP == 3 ? 32 : (sp ? 64 : R_arg);   // (the specialised kernels are only launched with these tile sizes)
+        // SP = 2: SP = 1 for a panel with two primers (one forward, one reverse: a single amplicon) -- the tile's 256
+        // alignments are one per lane, every LDS offset in front of the panel tables is a constant
+        NP = SP == 2 ? 2 : P->NP; NB = P->NB; S = SP == 3 ? 160 : (sp ? 80 : P->S); H = 2 * NP; MW = (S + 31) / 32; maxB = P->maxB;
+        need_starts = sp ? 0 : P->need_starts;
+        n_pbc = P->n_pbc; NPAIR = SP == 2 ? 1 : P->NPAIR;
+        npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
+        // (the default-flags kernels are lean bit-sliced launches by construction: no slots-mode state in them)
+        use_slots = SP != 0 ? 0 : use_slots_arg;
+        dbg_bdist = SP != 0 ? nullptr : dbg_bdist_arg;
+        use_bs = SP != 0 ? 1 : ((BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0);
+        ncand = 2 * NPAIR;
+        T = make_layout<PW>(NP, NB, S, R, maxB, need_starts, npmeta, sp ? 3 : P->kidx, use_slots, P->bs_ok, ncand,
+                            sp ? 0 : P->cap_hits, sp ? 0 : P->cap_ents, (sp && CM == 1) ? 256 : aux.nitems);
+        ppeq = (PW *)(lds + T.ppeq);        // [code][primer], stride NPs
+        prpeq = (PW *)(lds + T.prpeq);
+        bpeq = (unsigned *)(lds + T.bpeq);   // [code][barcode], stride NBs
+        bsre = (unsigned *)(lds + T.bsre);   // bit-sliced table [primer][row][code][word] (lean mode)
+        lut = lds + T.lut;
+        codes = lds + T.codes;
+        namask = (unsigned *)(lds + T.namask);
+        lensL = (int *)(lds + T.lens);
+        ocnt = (int *)(lds + T.ocnt);
+        rflag = (int *)(lds + T.rflag);
+        hits = (HitL *)(lds + T.hits);
+        masks = (unsigned *)(lds + T.masks);
+        tiem = (unsigned *)(lds + T.tiem);
+        bres = (unsigned *)(lds + T.bres);
+        dmask = (unsigned *)(lds + T.dmask);   // lean mode: [hit in round][distance][MBW] barcode bitmasks
+        ents = (EntL *)(lds + T.ents);
+        etail = (int *)(lds + T.etail);     // BSV == 3 only
+        offsA = (int *)(lds + T.offsA);    // exclusive scan of searched locations per hit
+        offsB = (int *)(lds + T.offsB);    // exclusive scan of searched hits (rank)
+        queue = (unsigned short *)(lds + T.queue);   // rank -> hit
+        cumL = (int *)(lds + T.emit);      // scorer: [read][candidate] accumulated trim shift
+        opsL = (smx_op *)(lds + T.opsL);
+        aggr = (int *)(lds + T.aggr);      // [0..7] counters, [8] round end rank, [9] next tile, [10] fallback items, [11] flagged alignments
+        hmap = (unsigned short *)(lds + T.hmap);     // compact mode: read * H + alignment -> record (T.NI = "no match")
+        clist = (unsigned short *)(lds + T.clist);   // compact mode: record -> read * H + alignment
+        pmask = (unsigned long long *)(lds + T.pmask);   // per read: alignments with a primer match
+        hcand = (unsigned long long *)(lds + T.hcand);   // per alignment: its candidates
+        cfilt = H <= 64 && NPAIR * 2 <= 64 && NPAIR * 2 > 4;   // the scorer looks at matched alignments' candidates only
+        tid = threadIdx.x;
+        wave = tid >> 6;
+        if (redo && tile_counter[1] == 0) {   // the usual redo launch: nothing on the list (every workgroup sees the same count:
+            if (tid == 0) workgroup_done();       // it is only zeroed once all of them have passed this point)
+            return false;
+        }
+        CS = T.CS; NPs = T.NPs; NBs = T.NBs; lNPs = T.lNPs; lNBs = T.lNBs; G = T.G; logG = T.logG; MBW = sp ? 1 : T.MBW;
+        stride = SP == 3 ? 320 : (sp ? 160 : P->wstride);
+        kidx = sp ? 3 : P->kidx; pfmin = P->pfmin;
+        preorient = sp ? 1 : P->preorient; minlen = sp ? -1 : P->minlen; maxlen = sp ? -1 : P->maxlen;
+        lH = (H & (H - 1)) == 0 ? 31 - __clz(H) : -1;
+        Hmagic = (unsigned)((0x100000000ull + (unsigned)H - 1) / (unsigned)H);
+        hcmagic = (unsigned)((0x100000000ull + (unsigned)(S >> 4) - 1) / (unsigned)((S >> 4) > 0 ? (S >> 4) : 1));   // chunk / (S/16)
+        redo_ratio = redo ? (uint32_t)((aux.Rc + R - 1) / R) : 1u;
+        n_tiles = redo ? tile_counter[1] * redo_ratio : (n_reads + R - 1) / R;
+        tacc = (unsigned long long *)(lds + T.tacc);   // [0..9] sums, [10] previous stamp
+        // (the default-flags kernels carry no phase timing: SMX_PHASE_TIMING runs use the generic instantiation)
+        dbg_phase = sp ? nullptr : P->dbg_phase;
+        timing = dbg_phase != nullptr && tid == 0;
+        SW = (R + 63) >> 6;              // scorer waves
+        return true;
+    }
+
+    __device__ __forceinline__ void stage_panel() {
+        // ---- phase 0: stage the panel (transposed: consecutive lanes = consecutive patterns hit distinct banks)
+        for (int i = tid; i < NP * 16; i += NT) {
+            int p = i >> 4, c = i & 15;
+            ppeq[c * NPs + p] = (PW)P->ppeq[i] << (PWBITS - P->pm[p]);   // left-aligned: row m-1 is the top bit
+            if (need_starts) prpeq[c * NPs + p] = (PW)P->prpeq[i];
+        }
+        if (!use_bs)
+            for (int i = tid; i < NB * 16; i += NT) bpeq[(i & 15) * NBs + (i >> 4)] = P->bpeq[i];
+        if (use_bs)
+            for (int i = tid; i < NP * T.MBW * 256; i += NT) {
+                int blk = i >> 8;   // (primer, word) block: [row][code], the row stride is a compile-time 16 words
+                bsre[blk * T.BSP + (i & 255)] = P->bs_re[i];
             }
-            if (pre_done) {
-            } else if (sizeof(PW) == 4 && g.j_lo == 0 && g.Sp == S && (S & 3) == 0) {
-                // common case (full window, 32-bit patterns): eight columns per unrolled block, one byte read per
-                // column (cheaper than unpacking a dword of codes: tools/ubench/primer_col.hip), uniform trip counts;
-                // the "new minimum" / "above minimum" flags are funnel-shifted into bit-reversed words
-                const unsigned *pq = (const unsigned *)ppeq + p;
-                unsigned Pu = ~0u, Mu = 0;
-                int sc = m, bst = m + 1;
-                const int esh = lNPs + 2;   // byte offset of Eq[code] = code << esh: one v_lshl_add per column
+        for (int i = tid; i < 512; i += NT) lut[i] = P->lut[i];
+        int *pmeta = (int *)(lds + T.pmeta);
+        {
+            int *q = pmeta;
+            LP.pm = q; q += NP; LP.pk = q; q += NP; LP.pdir = q; q += NP; LP.pfidx = q; q += NP;
+            LP.pbc_off = q; q += NP + 1; LP.pbc = q; q += n_pbc; LP.bm = q; q += NB;
+            LP.pair_f = q; q += NPAIR; LP.pair_r = q; q += NPAIR; LP.pair_pool = q;
+            for (int i = tid; i < NP; i += NT) {
+                pmeta[i] = P->pm[i]; pmeta[NP + i] = P->pk[i]; pmeta[2 * NP + i] = P->pdir[i]; pmeta[3 * NP + i] = P->pfidx[i];
+            }
+            for (int i = tid; i <= NP; i += NT) pmeta[4 * NP + i] = P->pbc_off[i];
+            for (int i = tid; i < n_pbc; i += NT) pmeta[5 * NP + 1 + i] = P->pbc[i];
+            for (int i = tid; i < NB; i += NT) pmeta[5 * NP + 1 + n_pbc + i] = P->bm[i];
+            for (int i = tid; i < NPAIR; i += NT) {
+                int *b = pmeta + 5 * NP + 1 + n_pbc + NB;
+                b[i] = P->pair_f[i]; b[NPAIR + i] = P->pair_r[i]; b[2 * NPAIR + i] = P->pair_pool[i];
+            }
+        }
+        if (tid < 12) aggr[tid] = 0;
+        for (int i = tid; i < R; i += NT) pmask[i] = 0ull;
+        if (cfilt) for (int i = tid; i < H; i += NT) hcand[i] = 0ull;
+        if (cmode && tid == 0) {   // the shared record of every alignment that is not flagged: what the primer scan writes for "no match"
+            HitL hn;
+            hn.tail_end = -1; hn.nloc = 0; hn.ntied = 0; hn.first_tied = -1; hn.pdist = -1; hn.bbest = -2; hn.jstar = 0; hn.fs_j = 0;
+            hn.flags = 0; hn.pad = 0;
+            hits[T.NI] = hn;
+            for (int w = 0; w < T.MBW; w++) tiem[T.NI * T.MBW + w] = 0;
+        }
+        __syncthreads();
+        if (cfilt)
+            for (int ci = tid; ci < NPAIR * 2; ci += NT) {   // candidate ci = (pair, orientation): its two alignments (cand_view)
+                const int pair = ci >> 1, o = ci & 1;
+                const int h1 = LP.pair_f[pair] * 2 + (o == 0 ? 0 : 1), h2 = LP.pair_r[pair] * 2 + (o == 0 ? 1 : 0);
+                atomicOr(&hcand[h1], 1ull << ci);
+                atomicOr(&hcand[h2], 1ull << ci);
+            }
+        __syncthreads();
+
+        if (timing) for (int i = 0; i < 11; i++) tacc[i] = 0;
+    }
+
+    // ---- phase 2, one alignment: primer scan, one lane per (read, primer, end).  With the prescan (pre != nullptr) every
+    // alignment it covers is decoded from its flag words; the others (windows with anything but upper-case ACGT) are queued
+    // and scanned afterwards, packed into the lowest lanes, so that one such read does not make its whole wave run
+    // the 80-column scalar scan.
+    __device__ __forceinline__ void primer_item(int item, const bool use_pre) {   // item = record index
+        const int dn = cmode ? (int)clist[item] : item;
+        int r = divH(dn), h = dn - __mul24(r, H), p = h >> 1, X = h & 1;
+        int L = lensC[r];
+        EndGeom g = end_geom(L, S);
+        const unsigned char *cw = codes + __mul24(r * 2 + X, CS);
+        const PW *peq = ppeq + p;
+        const int m = LP.pm[p], k = LP.pk[p], top = PWBITS - 1;
+        PW Pvv = ~(PW)0, Mv = 0;
+        int score = m, best = m + 1, jstar = 0, cnt = 0;
+        unsigned *mrow = masks + __mul24(item, MW);
+        // With the prescan: its flag words cover the window's first Sp columns = the whole stored window, which is the
+        // primer target unless the read is shorter than search_len AND its target starts inside the window
+        // (g.j_lo > 0): then only the orientation vote comes from the prescan (determine_orientation looks
+        // at the whole string) and the target [j_lo, Sp) -- at most search_len / 2 columns -- is scanned below.
+        bool pre_done = false, pre_omatch = false;
+        if (use_pre) {
+            const uint32_t gr = r0 + (uint32_t)r;   // flag words: [tile of 1024 reads][alignment h][chunk][read in tile]
+            const unsigned *pw = pre + ((size_t)(gr >> 10) * H + h) * (S >> 4) * PRE_TILE + (gr & (PRE_TILE - 1));
+            const int bfull = S == 160 ? prescan_decode<10>(pw, PRE_TILE, 10, MW, m, k, g.Sp, mrow, &jstar, &cnt)
+                            : S == 80 ? prescan_decode<5>(pw, PRE_TILE, 5, MW, m, k, g.Sp, mrow, &jstar, &cnt)   // the default -l
+                                      : prescan_decode<0>(pw, PRE_TILE, S >> 4, MW, m, k, g.Sp, mrow, &jstar, &cnt);
+            pre_omatch = bfull <= k;
+            if (g.j_lo == 0) { pre_done = true; best = pre_omatch ? bfull : m + 1; }
+            else { jstar = 0; cnt = 0; }
+        }
+        if (pre_done) {
+        } else if (sizeof(PW) == 4 && g.j_lo == 0 && g.Sp == S && (S & 3) == 0) {
+            // common case (full window, 32-bit patterns): eight columns per unrolled block, one byte read per
+            // column (cheaper than unpacking a dword of codes: tools/ubench/primer_col.hip), uniform trip counts;
+            // the "new minimum" / "above minimum" flags are funnel-shifted into bit-reversed words
+            const unsigned *pq = (const unsigned *)ppeq + p;
+            unsigned Pu = ~0u, Mu = 0;
+            int sc = m, bst = m + 1;
+            const int esh = lNPs + 2;   // byte offset of Eq[code] = code << esh: one v_lshl_add per column
 #define SMX_PCOL(J) do { const unsigned e_ = *(const unsigned *)((const char *)pq + ((unsigned)cw[J] << esh)); \
-                         myers_step_hw_top(e_, Pu, Mu, sc);                                              \
-                         ltw = __builtin_amdgcn_alignbit(ltw, (unsigned)(sc - bst), 31);                  \
-                         gtw = __builtin_amdgcn_alignbit(gtw, (unsigned)(bst - sc), 31);                  \
-                         bst = sc < bst ? sc : bst; } while (0)
-                for (int w = 0; w < MW; w++) {
-                    const int ncols = S - w * 32 < 32 ? S - w * 32 : 32;   // uniform, a multiple of 4
-                    // ltw: "new minimum" flags, gtw: "above the minimum" flags; the newest column is bit 0
-                    unsigned gtw = 0, ltw = 0;
-                    int j = w * 32;
-                    const int jend = j + ncols;
-                    for (; j + 8 <= jend; j += 8) {
-                        SMX_PCOL(j); SMX_PCOL(j + 1); SMX_PCOL(j + 2); SMX_PCOL(j + 3);
-                        SMX_PCOL(j + 4); SMX_PCOL(j + 5); SMX_PCOL(j + 6); SMX_PCOL(j + 7);
-                    }
-                    if (j < jend) { SMX_PCOL(j); SMX_PCOL(j + 1); SMX_PCOL(j + 2); SMX_PCOL(j + 3); }
-                    // column c of this word sits at bit ncols-1-c
-                    if (ncols > 0) {
-                        mrow[w] = __brev(~gtw) >> (32 - ncols);
-                        if (ltw) jstar = w * 32 + ncols - __ffs(ltw);
-                    } else mrow[w] = 0;
+                     myers_step_hw_top(e_, Pu, Mu, sc);                                              \
+                     ltw = __builtin_amdgcn_alignbit(ltw, (unsigned)(sc - bst), 31);                  \
+                     gtw = __builtin_amdgcn_alignbit(gtw, (unsigned)(bst - sc), 31);                  \
+                     bst = sc < bst ? sc : bst; } while (0)
+            for (int w = 0; w < MW; w++) {
+                const int ncols = S - w * 32 < 32 ? S - w * 32 : 32;   // uniform, a multiple of 4
+                // ltw: "new minimum" flags, gtw: "above the minimum" flags; the newest column is bit 0
+                unsigned gtw = 0, ltw = 0;
+                int j = w * 32;
+                const int jend = j + ncols;
+                for (; j + 8 <= jend; j += 8) {
+                    SMX_PCOL(j); SMX_PCOL(j + 1); SMX_PCOL(j + 2); SMX_PCOL(j + 3);
+                    SMX_PCOL(j + 4); SMX_PCOL(j + 5); SMX_PCOL(j + 6); SMX_PCOL(j + 7);
                 }
+                if (j < jend) { SMX_PCOL(j); SMX_PCOL(j + 1); SMX_PCOL(j + 2); SMX_PCOL(j + 3); }
+                // column c of this word sits at bit ncols-1-c
+                if (ncols > 0) {
+                    mrow[w] = __brev(~gtw) >> (32 - ncols);
+                    if (ltw) jstar = w * 32 + ncols - __ffs(ltw);
+                } else mrow[w] = 0;
+            }
 #undef SMX_PCOL
-                best = bst; score = sc;
-                Pvv = (PW)Pu; Mv = (PW)Mu;
-                for (int w = jstar >> 5; w < MW; w++) {
-                    unsigned word = mrow[w];
-                    if (w == (jstar >> 5)) word &= ~0u << (jstar & 31);
-                    cnt += __popc(word);
-                }
-            } else if (g.j_lo == 0) {
-                // common case: the target is the whole stored window; branch-free bookkeeping per column
-                const int Sp = g.Sp;
-                for (int w = 0; w < MW; w++) {
-                    unsigned word = 0;
-                    int jend = (w + 1) * 32 < Sp ? (w + 1) * 32 : Sp;
+            best = bst; score = sc;
+            Pvv = (PW)Pu; Mv = (PW)Mu;
+            for (int w = jstar >> 5; w < MW; w++) {
+                unsigned word = mrow[w];
+                if (w == (jstar >> 5)) word &= ~0u << (jstar & 31);
+                cnt += __popc(word);
+            }
+        } else if (g.j_lo == 0) {
+            // common case: the target is the whole stored window; branch-free bookkeeping per column
+            const int Sp = g.Sp;
+            for (int w = 0; w < MW; w++) {
+                unsigned word = 0;
+                int jend = (w + 1) * 32 < Sp ? (w + 1) * 32 : Sp;
 #pragma unroll 4
-                    for (int j = w * 32; j < jend; j++) {
-                        myers_step<PW, false>(peq[(int)cw[j] << lNPs], Pvv, Mv, score, top);
-                        bool lt = score < best;
-                        best = lt ? score : best;
-                        jstar = lt ? j : jstar;
-                        word |= (score == best ? 1u : 0u) << (j & 31);
-                    }
-                    mrow[w] = word;
-                }
-                // number of optimal ends = bits at or after the first occurrence of the final minimum
-                for (int w = jstar >> 5; w < MW; w++) {
-                    unsigned word = mrow[w];
-                    if (w == (jstar >> 5)) word &= ~0u << (jstar & 31);
-                    cnt += __popc(word);
-                }
-            } else {
-                for (int w = 0; w < MW; w++) mrow[w] = 0;
-                for (int j = g.j_lo; j < g.Sp; j++) {
+                for (int j = w * 32; j < jend; j++) {
                     myers_step<PW, false>(peq[(int)cw[j] << lNPs], Pvv, Mv, score, top);
-                    if (score < best) { best = score; jstar = j; cnt = 0; }
-                    if (score == best) { cnt++; mrow[j >> 5] |= 1u << (j & 31); }   // bits before jstar are stale: ignored
+                    bool lt = score < best;
+                    best = lt ? score : best;
+                    jstar = lt ? j : jstar;
+                    word |= (score == best ? 1u : 0u) << (j & 31);
                 }
+                mrow[w] = word;
             }
-            bool matched = best <= k;
-            bool omatch = matched;
-            if (g.j_lo > 0 && use_pre) omatch = pre_omatch;
-            else if (g.j_lo > 0) {   // short read: determine_orientation looks at the whole string (Q1)
-                PW P2 = ~(PW)0, M2 = 0;
-                int sc = m, b2 = m + 1;
-                for (int j = 0; j < g.Sp; j++) {
-                    myers_step<PW, false>(peq[(int)cw[j] << lNPs], P2, M2, sc, top);
-                    b2 = sc < b2 ? sc : b2;
-                }
-                omatch = b2 <= k;
+            // number of optimal ends = bits at or after the first occurrence of the final minimum
+            for (int w = jstar >> 5; w < MW; w++) {
+                unsigned word = mrow[w];
+                if (w == (jstar >> 5)) word &= ~0u << (jstar & 31);
+                cnt += __popc(word);
             }
-            int fs_j = jstar;
-            if (matched && need_starts) {
-                // edlib's start rule: SHW of the reversed pattern over the reversed target prefix,
-                // LAST optimal position = smallest start
-                const PW *rpeq = prpeq + p;
-                PW P2 = ~(PW)0, M2 = 0;
-                int sc = m, lastc = 1;
-                int maxc = m + best;
-                for (int c = 1; c <= maxc; c++) {
-                    int j = jstar - (c - 1);
-                    if (j < g.j_lo) break;
-                    myers_step<PW, true>(rpeq[(int)cw[j] << lNPs], P2, M2, sc, m - 1);   // rpeq is right-aligned
-                    if (sc == best) lastc = c;
-                }
-                fs_j = jstar - (lastc - 1);
+        } else {
+            for (int w = 0; w < MW; w++) mrow[w] = 0;
+            for (int j = g.j_lo; j < g.Sp; j++) {
+                myers_step<PW, false>(peq[(int)cw[j] << lNPs], Pvv, Mv, score, top);
+                if (score < best) { best = score; jstar = j; cnt = 0; }
+                if (score == best) { cnt++; mrow[j >> 5] |= 1u << (j & 31); }   // bits before jstar are stale: ignored
             }
-            HitL hl;
-            hl.tail_end = -1;
-            hl.pdist = (signed char)(matched ? best : -1);
-            hl.nloc = (short)(matched ? cnt : 0);
-            hl.bbest = -2; hl.ntied = 0; hl.first_tied = -1;
-            hl.jstar = (unsigned char)jstar; hl.fs_j = (unsigned char)fs_j;
-            hl.flags = (unsigned char)(omatch ? 1 : 0); hl.pad = 0;
-            hits[item] = hl;
-            if (cfilt && matched) atomicOr(&pmask[r], 1ull << h);
-            if (omatch) {
-                // determine_orientation via A.6: fwd primer in A / rev primer in B vote "forward"
-                int dir = LP.pdir[p];
-                int vote_fwd = (dir == 0) ? (X == 0) : (X == 1);
-                atomicAdd(&ocntC[r], vote_fwd ? 1 : 0x10000);
+        }
+        bool matched = best <= k;
+        bool omatch = matched;
+        if (g.j_lo > 0 && use_pre) omatch = pre_omatch;
+        else if (g.j_lo > 0) {   // short read: determine_orientation looks at the whole string (Q1)
+            PW P2 = ~(PW)0, M2 = 0;
+            int sc = m, b2 = m + 1;
+            for (int j = 0; j < g.Sp; j++) {
+                myers_step<PW, false>(peq[(int)cw[j] << lNPs], P2, M2, sc, top);
+                b2 = sc < b2 ? sc : b2;
             }
-        };
+            omatch = b2 <= k;
+        }
+        int fs_j = jstar;
+        if (matched && need_starts) {
+            // edlib's start rule: SHW of the reversed pattern over the reversed target prefix,
+            // LAST optimal position = smallest start
+            const PW *rpeq = prpeq + p;
+            PW P2 = ~(PW)0, M2 = 0;
+            int sc = m, lastc = 1;
+            int maxc = m + best;
+            for (int c = 1; c <= maxc; c++) {
+                int j = jstar - (c - 1);
+                if (j < g.j_lo) break;
+                myers_step<PW, true>(rpeq[(int)cw[j] << lNPs], P2, M2, sc, m - 1);   // rpeq is right-aligned
+                if (sc == best) lastc = c;
+            }
+            fs_j = jstar - (lastc - 1);
+        }
+        HitL hl;
+        hl.tail_end = -1;
+        hl.pdist = (signed char)(matched ? best : -1);
+        hl.nloc = (short)(matched ? cnt : 0);
+        hl.bbest = -2; hl.ntied = 0; hl.first_tied = -1;
+        hl.jstar = (unsigned char)jstar; hl.fs_j = (unsigned char)fs_j;
+        hl.flags = (unsigned char)(omatch ? 1 : 0); hl.pad = 0;
+        hits[item] = hl;
+        if (cfilt && matched) atomicOr(&pmask[r], 1ull << h);
+        if (omatch) {
+            // determine_orientation via A.6: fwd primer in A / rev primer in B vote "forward"
+            int dir = LP.pdir[p];
+            int vote_fwd = (dir == 0) ? (X == 0) : (X == 1);
+            atomicAdd(&ocntC[r], vote_fwd ? 1 : 0x10000);
+        }
+    }
+
+    __device__ __forceinline__ void phase2_primers() {
+        unsigned short *fbq = queue;   // fallback items (the rank -> hit queue is not live before phase 3a)
         if (cmode) {
             // which alignments get a record: the ones the prescan flags, and every alignment of a read the prescan
             // does not cover (rflag).  All match-word loads of a batch are issued before the first is used.
@@ -1481,78 +1522,80 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             for (int item = tid; item < nI; item += NT) primer_item(item, false);
             __syncthreads();
         }
-        STAMP(1);
-        if (live) {
 
-        // ---- phase 3a: orientation, which ends need barcodes; block-wide scans of locations and searched hits;
-        //      one *entry* per optimal primer location of every searched hit
+    }
+
+    // ---- phase 3a helpers: which ends need barcodes (find_candidate_matches:677-741) -> number of locations to search
+    __device__ __forceinline__ int locations_needed(int item) {
+        const int dn = cmode ? (int)clist[item] : item;
+        int r = divH(dn), h = dn - __mul24(r, H), p = h >> 1, X = h & 1;
+        int L = lensC[r];
+        int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
+        int ori = 3;   // bit0: as-read candidates allowed, bit1: reverse-complement candidates allowed
+        if (preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
+        bool filtered = (minlen != -1 && L < minlen) || (maxlen != -1 && L > maxlen);
+        int dir = LP.pdir[p];
+        bool in_fwd = (dir == 0) ? (X == 0) : (X == 1);   // used by as-read candidates
+        bool needed = !filtered && ((in_fwd && (ori & 1)) || (!in_fwd && (ori & 2)));
+        HitL &hl = hits[item];
+        int n = 0;
+        if (needed && hl.pdist >= 0) {
+            hl.flags |= 2;
+            hl.bbest = -1;
+            n = hl.nloc;
+        }
+        for (int w = 0; w < MBW; w++) tiem[__mul24(item, MBW) + w] = 0;
+        return n;
+    }
+    // the optimal locations of one searched hit -> entries e, e+1, ... (target start, prefilter verdict)
+    __device__ __forceinline__ void list_entries(int item, int rank_in_round, int e) {
+        const int dn = cmode ? (int)clist[item] : item;
+        int r = divH(dn), h = dn - __mul24(r, H), X = h & 1;
+        const HitL &hl = hits[item];
+        int L = lensC[r];
+        EndGeom g = end_geom(L, S);
+        const unsigned *mrow = masks + __mul24(item, MW);
+        const unsigned *na = namask + __mul24(r * 2 + X, MW);
+        int ord = 0;
+        for (int w = hl.jstar >> 5; w < MW; w++) {
+            unsigned word = mrow[w];
+            if (w == (hl.jstar >> 5)) word &= ~0u << (hl.jstar & 31);
+            while (word) {
+                int je = w * 32 + __ffs(word) - 1;
+                word &= word - 1;
+                int bstart = (je - g.j_lo) + g.shift + 1;
+                BcGeom bg = bc_geom(L, g.base, bstart);
+                int ncol = g.Sp - bg.tj0;
+                bool ok = ncol > 0;
+                if (ok && pfmin > 0) {   // exact-set restatement of BloomPrefilter.match (Q7)
+                    if (!bg.pf_same || ncol < pfmin) ok = false;
+                    else {   // any non-ACGT code among target[0 : pfmin) ?
+                        int wi = bg.tj0 >> 5, sh = bg.tj0 & 31;
+                        unsigned long long two = ((unsigned long long)(wi + 1 < MW ? na[wi + 1] : 0u) << 32) | na[wi];
+                        if ((two >> sh) & ((1ull << pfmin) - 1ull)) ok = false;
+                    }
+                }
+                EntL en;
+                en.hit = (unsigned short)item;
+                en.slot = (unsigned short)(rank_in_round << logG);
+                en.tj0 = (unsigned char)(ok ? bg.tj0 : 0);
+                en.loc_ord = (unsigned char)ord;
+                en.ncol = (unsigned char)(ncol > 255 ? 255 : (ncol < 0 ? 0 : ncol));
+                en.ok = ok ? 1 : 0;
+                en.delta = (short)bg.delta; en.pad = 0;
+                ents[e++] = en;
+                ord++;
+            }
+        }
+    }
+
+    // ---- phase 3a: orientation, which ends need barcodes; block-wide scans of locations and searched hits;
+    //      one *entry* per optimal primer location of every searched hit
+    __device__ __forceinline__ void phase3a_entries() {
         if (dbg_bdist)   // (slots mode only: never compact)
             for (int i = tid; i < nh * maxB; i += NT) dbg_bdist[(size_t)r0 * H * maxB + i] = -1;
-        // which ends need barcodes (find_candidate_matches:677-741) -> number of locations to search
-        auto locations_needed = [&](int item) -> int {
-            const int dn = cmode ? (int)clist[item] : item;
-            int r = divH(dn), h = dn - __mul24(r, H), p = h >> 1, X = h & 1;
-            int L = lensC[r];
-            int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
-            int ori = 3;   // bit0: as-read candidates allowed, bit1: reverse-complement candidates allowed
-            if (preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
-            bool filtered = (minlen != -1 && L < minlen) || (maxlen != -1 && L > maxlen);
-            int dir = LP.pdir[p];
-            bool in_fwd = (dir == 0) ? (X == 0) : (X == 1);   // used by as-read candidates
-            bool needed = !filtered && ((in_fwd && (ori & 1)) || (!in_fwd && (ori & 2)));
-            HitL &hl = hits[item];
-            int n = 0;
-            if (needed && hl.pdist >= 0) {
-                hl.flags |= 2;
-                hl.bbest = -1;
-                n = hl.nloc;
-            }
-            for (int w = 0; w < MBW; w++) tiem[__mul24(item, MBW) + w] = 0;
-            return n;
-        };
-        // the optimal locations of one searched hit -> entries e, e+1, ... (target start, prefilter verdict)
-        auto list_entries = [&](int item, int rank_in_round, int e) {
-            const int dn = cmode ? (int)clist[item] : item;
-            int r = divH(dn), h = dn - __mul24(r, H), X = h & 1;
-            const HitL &hl = hits[item];
-            int L = lensC[r];
-            EndGeom g = end_geom(L, S);
-            const unsigned *mrow = masks + __mul24(item, MW);
-            const unsigned *na = namask + __mul24(r * 2 + X, MW);
-            int ord = 0;
-            for (int w = hl.jstar >> 5; w < MW; w++) {
-                unsigned word = mrow[w];
-                if (w == (hl.jstar >> 5)) word &= ~0u << (hl.jstar & 31);
-                while (word) {
-                    int je = w * 32 + __ffs(word) - 1;
-                    word &= word - 1;
-                    int bstart = (je - g.j_lo) + g.shift + 1;
-                    BcGeom bg = bc_geom(L, g.base, bstart);
-                    int ncol = g.Sp - bg.tj0;
-                    bool ok = ncol > 0;
-                    if (ok && pfmin > 0) {   // exact-set restatement of BloomPrefilter.match (Q7)
-                        if (!bg.pf_same || ncol < pfmin) ok = false;
-                        else {   // any non-ACGT code among target[0 : pfmin) ?
-                            int wi = bg.tj0 >> 5, sh = bg.tj0 & 31;
-                            unsigned long long two = ((unsigned long long)(wi + 1 < MW ? na[wi + 1] : 0u) << 32) | na[wi];
-                            if ((two >> sh) & ((1ull << pfmin) - 1ull)) ok = false;
-                        }
-                    }
-                    EntL en;
-                    en.hit = (unsigned short)item;
-                    en.slot = (unsigned short)(rank_in_round << logG);
-                    en.tj0 = (unsigned char)(ok ? bg.tj0 : 0);
-                    en.loc_ord = (unsigned char)ord;
-                    en.ncol = (unsigned char)(ncol > 255 ? 255 : (ncol < 0 ? 0 : ncol));
-                    en.ok = ok ? 1 : 0;
-                    en.delta = (short)bg.delta; en.pad = 0;
-                    ents[e++] = en;
-                    ord++;
-                }
-            }
-        };
-        bool prelisted = false;   // the usual case: one item per lane and everything fits one round ->
-        int nq = 0, nE_pre = 0;   // scans by shuffles, entries listed by the hit's own lane, three barriers fewer
+        prelisted = false;   // the usual case: one item per lane and everything fits one round ->
+        nq = 0; nE_pre = 0;  // scans by shuffles, entries listed by the hit's own lane, three barriers fewer
         if (nI <= NT) {
             const int item = tid;
             const int n = item < nI ? locations_needed(item) : 0;
@@ -1606,9 +1649,246 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             nq = offsB[nI];
             __syncthreads();
         }
-        STAMP(2);
 
-        // ---- phase 3b/3c in rounds of at most CAPH searched hits and CAPE (hit, location) entries
+    }
+
+    // 3b: barcode scan of the round's nE entries
+    __device__ __forceinline__ void phase3b_barcodes(int nE) {
+        // 3b (lean, uniform barcode length): bit-sliced scan, one lane per (entry, 32-barcode word).  Two separate
+        // loops (k is uniform for the launch) so that the register allocation of one variant never meets the other's.
+        if (BSV != 0 && use_bs) {
+            const int bsm = P->bs_m;
+            for (int item = tid; item < nE * MBW; item += NT) {
+                int ei = item, w = 0;
+                if (MBW != 1) { ei = item / MBW; w = item - ei * MBW; }   // MBW == 1 (<= 32 barcodes per primer) is the usual case
+                const EntL en = ents[ei];
+                if (BSV == 3) etail[ei] = -0x7FFFFFFF;
+                if (!en.ok) continue;
+                const int hh = cmode ? (int)clist[en.hit] : (int)en.hit, r = divH(hh), h = hh - __mul24(r, H), p = h >> 1, X = h & 1;
+                const unsigned char *cwt = codes + __mul24(r * 2 + X, CS) + en.tj0;
+                unsigned *dm = dmask + __mul24(__mul24(en.slot >> logG, kidx + 1), MBW) + w;
+                if constexpr (BSV == 3) {
+                    unsigned seen[4], ML[4];
+                    const unsigned want[4] = {~0u, ~0u, ~0u, ~0u};
+                    int tc = -1;
+                    const unsigned *reb = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
+                    if (bsm == 13) bitsliced_shw_pad_tails<3, 13>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                    else if (bsm <= 8 && bsm > 3) bitsliced_shw_pad_tails<3, 8>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                    else if (bsm <= 12 && bsm > 3) bitsliced_shw_pad_tails<3, 12>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                    else bitsliced_shw_pad_tails<3, 16>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                    // end of the kept alignment in reference coordinates, valid as the hit's tail if this is its only
+                    // location (the summary redoes hits with several locations)
+                    etail[ei] = tc >= 0 ? (int)en.tj0 + tc + end_geom(lensC[r], S).base - (int)en.delta : -0x7FFFFFFF;
+#pragma unroll
+                    for (int d = 0; d < 4; d++)
+                        if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
+                } else if constexpr (BSV == 1) {
+                    unsigned seen[4];
+                    // padded height: the smallest instantiated M >= barcode length (uniform branch)
+                    const unsigned *reb = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
+                    if (bsm == 13) bitsliced_shw_pad<3, 13>(reb, cwt, en.ncol, bsm, kidx, seen);
+                    else if (bsm <= 8 && bsm > 3) bitsliced_shw_pad<3, 8>(reb, cwt, en.ncol, bsm, kidx, seen);
+                    else if (bsm <= 12 && bsm > 3) bitsliced_shw_pad<3, 12>(reb, cwt, en.ncol, bsm, kidx, seen);
+                    else bitsliced_shw_pad<3, 16>(reb, cwt, en.ncol, bsm, kidx, seen);
+#pragma unroll
+                    for (int d = 0; d < 4; d++)
+                        if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
+                } else if constexpr (BSV == 2) {
+                    unsigned seen[8];
+                    const unsigned *reb8 = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
+                    if (kidx == 4 && bsm > 4 && bsm <= 16) {   // k = 4: the padded straight-line scan with a 9-row window
+                        unsigned s5[5];
+                        if (bsm == 13) bitsliced_shw_pad<4, 13>(reb8, cwt, en.ncol, bsm, kidx, s5);
+                        else bitsliced_shw_pad<4, 16>(reb8, cwt, en.ncol, bsm, kidx, s5);
+#pragma unroll
+                        for (int d = 0; d < 8; d++) seen[d] = d < 5 ? s5[d] : 0u;
+                    } else
+                        bitsliced_shw<8>(reb8, cwt, en.ncol, bsm, kidx, seen);
+#pragma unroll
+                    for (int d = 0; d < 8; d++)
+                        if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
+                }
+            }
+        } else
+        // 3b: barcode scan, one lane per (entry, barcode slot)
+        for (int item = tid; item < (nE << logG); item += NT) {
+            const EntL en = ents[item >> logG];
+            int bi = item & (G - 1);
+            int hh = cmode ? (int)clist[en.hit] : (int)en.hit, r = divH(hh), h = hh - __mul24(r, H), p = h >> 1, X = h & 1;
+            int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
+            if (bi >= nb || !en.ok) continue;
+            int gb = LP.pbc[LP.pbc_off[p] + bi];
+            int m = LP.bm[gb], top = m - 1;
+            const unsigned char *cw = codes + (r * 2 + X) * CS + en.tj0;
+            int ncol = en.ncol < m + kidx ? en.ncol : m + kidx;
+            const unsigned *peq = bpeq + gb;
+            unsigned Pvv = ~0u, Mv = 0;
+            int score = m, best = m + 1, firstc = 0, lastc = 0;
+#pragma unroll 4
+            for (int c = 0; c < ncol; c++) {
+                myers_step<unsigned, true>(peq[(int)cw[c] << lNBs], Pvv, Mv, score, top);
+                bool lt = score < best;
+                best = lt ? score : best;
+                firstc = lt ? c : firstc;
+                lastc = (score == best) ? c : lastc;
+            }
+            if (best <= kidx) {
+                if (use_slots)
+                    atomicMin(&bres[en.slot + bi], ((unsigned)best << 24) | ((unsigned)en.loc_ord << 16) |
+                                                       ((unsigned)(en.tj0 + firstc) << 8) | (unsigned)(en.tj0 + lastc));
+                else   // barcode bi seen at distance `best` (any location): the lowest non-empty level wins
+                    atomicOr(&dmask[(((en.slot >> logG) * (kidx + 1)) + best) * MBW + (bi >> 5)], 1u << (bi & 31));
+            }
+        }
+
+    }
+
+    __device__ __forceinline__ void phase3c_summary(int q0, int q1, int e_base) {
+        // 3c: per searched hit: best distance, tie set (ballot), tails extent.  Lanes = (hit, barcode slot):
+        // group-of-G reductions by xor-shuffles, the tie bitmask straight from the ballot.
+        if (!use_slots) {
+            // lean mode: best = lowest distance level with any barcode, tie set = that level's bitmask
+            for (int q = q0 + tid; q < q1; q += NT) {
+                int item = queue[q];
+                const unsigned *dm = dmask + (q - q0) * (kidx + 1) * MBW;
+                for (int d = 0; d <= kidx; d++) {
+                    int nt = 0, first = -1;
+                    for (int w = 0; w < MBW; w++) {
+                        unsigned m = dm[d * MBW + w];
+                        if (m && first < 0) first = w * 32 + __ffs(m) - 1;
+                        nt += __popc(m);
+                    }
+                    if (nt) {
+                        HitL &hl = hits[item];
+                        hl.bbest = (signed char)d; hl.ntied = (short)nt; hl.first_tied = (short)first;
+                        for (int w = 0; w < MBW; w++) tiem[item * MBW + w] = dm[d * MBW + w];
+                        break;
+                    }
+                }
+                if constexpr (BSV == 3) {
+                    // --trim tails: max over the within-k barcodes of the last optimal end of the alignment the
+                    // reference keeps for each (its FIRST location at its best distance, match_one_end :806-811)
+                    HitL &hl = hits[item];
+                    if (hl.bbest >= 0) {
+                        const int ne = hl.nloc, e0 = offsA[item] - e_base;
+                        int t = -0x7FFFFFFF;
+                        if (ne == 1) t = etail[e0];
+                        else {
+                            const int dn = cmode ? (int)clist[item] : item;
+                            const int r = divH(dn), h = dn - __mul24(r, H), p = h >> 1, X = h & 1;
+                            const int base = end_geom(lensC[r], S).base, bsm = P->bs_m;
+                            const unsigned *reb = bsre + __mul24(p, T.BSP);   // MBW == 1 on this path
+                            unsigned GM[4], prev[4] = {0u, 0u, 0u, 0u}, lower = 0;
+#pragma unroll
+                            for (int d = 0; d < 4; d++) { GM[d] = d <= kidx ? (dm[d] & ~lower) : 0u; lower |= d <= kidx ? dm[d] : 0u; }
+                            for (int e = e0; e < e0 + ne; e++) {
+                                const EntL en = ents[e];
+                                if (!en.ok) continue;
+                                unsigned want[4], seen[4], ML[4];
+#pragma unroll
+                                for (int d = 0; d < 4; d++) want[d] = GM[d] & ~prev[d];
+                                if (!(want[0] | want[1] | want[2] | want[3])) break;   // every barcode has its location
+                                const unsigned char *cwt = codes + __mul24(r * 2 + X, CS) + en.tj0;
+                                int tc = -1;
+                                if (bsm == 13) bitsliced_shw_pad_tails<3, 13>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                                else if (bsm <= 8 && bsm > 3) bitsliced_shw_pad_tails<3, 8>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                                else if (bsm <= 12 && bsm > 3) bitsliced_shw_pad_tails<3, 12>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                                else bitsliced_shw_pad_tails<3, 16>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
+                                if (tc >= 0) { int v = (int)en.tj0 + tc + base - (int)en.delta; t = v > t ? v : t; }
+#pragma unroll
+                                for (int d = 0; d < 4; d++) prev[d] |= ML[d] & GM[d];
+                            }
+                        }
+                        hl.tail_end = t;
+                    }
+                }
+            }
+        } else if (G <= 64) {
+            const int nslots = (q1 - q0) << logG;
+            for (int base_i = wave * 64; base_i < nslots; base_i += NT) {
+                const int i = base_i + (tid & 63);
+                const bool in = i < nslots;
+                const int q = q0 + ((in ? i : 0) >> logG), sl = i & (G - 1);
+                const int item = queue[q];
+                const int r = divH(item), h = item - __mul24(r, H), p = h >> 1;
+                const int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
+                const bool live = in && sl < nb;
+                unsigned v = live ? bres[i] : 0xFFFFFFFFu;
+                if (live && dbg_bdist)
+                    dbg_bdist[(size_t)r0 * H * maxB + (size_t)item * maxB + sl] = (v == 0xFFFFFFFFu) ? (int8_t)-1 : (int8_t)(v >> 24);
+                const int L = lensC[r];
+                const EndGeom g = end_geom(L, S);
+                int last_abs = -0x7FFFFFFF;
+                if (v != 0xFFFFFFFFu) {
+                    int delta = 0;
+                    if (L < S) {   // short read: the location's slice start may have wrapped (Q1)
+                        int je = nth_location(masks + (size_t)item * MW, MW, hits[item].jstar, (v >> 16) & 0xFF);
+                        delta = bc_geom(L, g.base, (je - g.j_lo) + g.shift + 1).delta;
+                    }
+                    last_abs = (int)(v & 0xFF) + g.base - delta;
+                }
+                unsigned dmin = v >> 24;
+                int tail = last_abs;
+                for (int d = 1; d < G; d <<= 1) {
+                    unsigned o = (unsigned)__shfl_xor((int)dmin, d, 64);
+                    int t = __shfl_xor(tail, d, 64);
+                    dmin = o < dmin ? o : dmin;
+                    tail = t > tail ? t : tail;
+                }
+                const bool tied = (v >> 24) == dmin && dmin != 255;
+                unsigned long long bal = __ballot(tied);
+                const int gshift = (tid & 63) & ~(G - 1);
+                unsigned long long gm = (G == 64) ? bal : ((bal >> gshift) & ((1ull << G) - 1ull));
+                int first = gm ? __ffsll((long long)gm) - 1 : 0;
+                if (in && sl == 0 && dmin != 255) {
+                    HitL &hl = hits[item];
+                    hl.bbest = (signed char)dmin; hl.ntied = (short)__popcll(gm); hl.first_tied = (short)first;
+                    hl.tail_end = tail;
+                    tiem[item * MBW] = (unsigned)gm;
+                    if (MBW > 1) tiem[item * MBW + 1] = (unsigned)(gm >> 32);
+                }
+            }
+        } else
+        for (int q = q0 + tid; q < q1; q += NT) {
+            int item = queue[q];
+            HitL &hl = hits[item];
+            int r = divH(item), h = item - __mul24(r, H), p = h >> 1;
+            int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
+            const unsigned *br = bres + ((q - q0) << logG);
+            unsigned best = 255;
+            for (int i = 0; i < nb; i++) { unsigned d = br[i] >> 24; best = d < best ? d : best; }
+            if (dbg_bdist)
+                for (int i = 0; i < nb; i++)
+                    dbg_bdist[(size_t)r0 * H * maxB + (size_t)item * maxB + i] =
+                        (br[i] == 0xFFFFFFFFu) ? (int8_t)-1 : (int8_t)(br[i] >> 24);
+            if (best == 255) continue;
+            int L = lensC[r];
+            EndGeom g = end_geom(L, S);
+            int ntied = 0, first = -1, tail = -0x7FFFFFFF;
+            for (int i = 0; i < nb; i++) {
+                unsigned v = br[i];
+                if (v == 0xFFFFFFFFu) continue;
+                int delta = 0;
+                if (L < S) {   // short read: the location's slice start may have wrapped (Q1)
+                    int je = nth_location(masks + (size_t)item * MW, MW, hl.jstar, (v >> 16) & 0xFF);
+                    delta = bc_geom(L, g.base, (je - g.j_lo) + g.shift + 1).delta;
+                }
+                int last_abs = (int)(v & 0xFF) + g.base - delta;
+                tail = last_abs > tail ? last_abs : tail;
+                if ((v >> 24) == best) {
+                    if (ntied == 0) first = i;
+                    ntied++;
+                    tiem[item * MBW + (i >> 5)] |= 1u << (i & 31);
+                }
+            }
+            hl.bbest = (signed char)best; hl.ntied = (short)ntied; hl.first_tied = (short)first;
+            hl.tail_end = tail;
+        }
+
+    }
+
+    // ---- phase 3b/3c in rounds of at most CAPH searched hits and CAPE (hit, location) entries
+    __device__ __forceinline__ void phase3_rounds() {
         for (int q0 = 0; q0 < nq;) {
             int q1, nE, e_base = 0;
             if (prelisted) { q1 = nq; nE = nE_pre; }
@@ -1638,412 +1918,190 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
                 else { for (int i = tid; i < (q1 - q0) * (kidx + 1) * MBW; i += NT) dmask[i] = 0; }
                 __syncthreads();
             }
-            STAMP(3);
-
-            // 3b (lean, uniform barcode length): bit-sliced scan, one lane per (entry, 32-barcode word).  Two separate
-            // loops (k is uniform for the launch) so that the register allocation of one variant never meets the other's.
-            if (BSV != 0 && use_bs) {
-                const int bsm = P->bs_m;
-                for (int item = tid; item < nE * MBW; item += NT) {
-                    int ei = item, w = 0;
-                    if (MBW != 1) { ei = item / MBW; w = item - ei * MBW; }   // MBW == 1 (<= 32 barcodes per primer) is the usual case
-                    const EntL en = ents[ei];
-                    if (BSV == 3) etail[ei] = -0x7FFFFFFF;
-                    if (!en.ok) continue;
-                    const int hh = cmode ? (int)clist[en.hit] : (int)en.hit, r = divH(hh), h = hh - __mul24(r, H), p = h >> 1, X = h & 1;
-                    const unsigned char *cwt = codes + __mul24(r * 2 + X, CS) + en.tj0;
-                    unsigned *dm = dmask + __mul24(__mul24(en.slot >> logG, kidx + 1), MBW) + w;
-                    if constexpr (BSV == 3) {
-                        unsigned seen[4], ML[4];
-                        const unsigned want[4] = {~0u, ~0u, ~0u, ~0u};
-                        int tc = -1;
-                        const unsigned *reb = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
-                        if (bsm == 13) bitsliced_shw_pad_tails<3, 13>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
-                        else if (bsm <= 8 && bsm > 3) bitsliced_shw_pad_tails<3, 8>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
-                        else if (bsm <= 12 && bsm > 3) bitsliced_shw_pad_tails<3, 12>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
-                        else bitsliced_shw_pad_tails<3, 16>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
-                        // end of the kept alignment in reference coordinates, valid as the hit's tail if this is its only
-                        // location (the summary redoes hits with several locations)
-                        etail[ei] = tc >= 0 ? (int)en.tj0 + tc + end_geom(lensC[r], S).base - (int)en.delta : -0x7FFFFFFF;
-#pragma unroll
-                        for (int d = 0; d < 4; d++)
-                            if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
-                    } else if constexpr (BSV == 1) {
-                        unsigned seen[4];
-                        // padded height: the smallest instantiated M >= barcode length (uniform branch)
-                        const unsigned *reb = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
-                        if (bsm == 13) bitsliced_shw_pad<3, 13>(reb, cwt, en.ncol, bsm, kidx, seen);
-                        else if (bsm <= 8 && bsm > 3) bitsliced_shw_pad<3, 8>(reb, cwt, en.ncol, bsm, kidx, seen);
-                        else if (bsm <= 12 && bsm > 3) bitsliced_shw_pad<3, 12>(reb, cwt, en.ncol, bsm, kidx, seen);
-                        else bitsliced_shw_pad<3, 16>(reb, cwt, en.ncol, bsm, kidx, seen);
-#pragma unroll
-                        for (int d = 0; d < 4; d++)
-                            if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
-                    } else if constexpr (BSV == 2) {
-                        unsigned seen[8];
-                        const unsigned *reb8 = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
-                        if (kidx == 4 && bsm > 4 && bsm <= 16) {   // k = 4: the padded straight-line scan with a 9-row window
-                            unsigned s5[5];
-                            if (bsm == 13) bitsliced_shw_pad<4, 13>(reb8, cwt, en.ncol, bsm, kidx, s5);
-                            else bitsliced_shw_pad<4, 16>(reb8, cwt, en.ncol, bsm, kidx, s5);
-#pragma unroll
-                            for (int d = 0; d < 8; d++) seen[d] = d < 5 ? s5[d] : 0u;
-                        } else
-                            bitsliced_shw<8>(reb8, cwt, en.ncol, bsm, kidx, seen);
-#pragma unroll
-                        for (int d = 0; d < 8; d++)
-                            if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
-                    }
-                }
-            } else
-            // 3b: barcode scan, one lane per (entry, barcode slot)
-            for (int item = tid; item < (nE << logG); item += NT) {
-                const EntL en = ents[item >> logG];
-                int bi = item & (G - 1);
-                int hh = cmode ? (int)clist[en.hit] : (int)en.hit, r = divH(hh), h = hh - __mul24(r, H), p = h >> 1, X = h & 1;
-                int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
-                if (bi >= nb || !en.ok) continue;
-                int gb = LP.pbc[LP.pbc_off[p] + bi];
-                int m = LP.bm[gb], top = m - 1;
-                const unsigned char *cw = codes + (r * 2 + X) * CS + en.tj0;
-                int ncol = en.ncol < m + kidx ? en.ncol : m + kidx;
-                const unsigned *peq = bpeq + gb;
-                unsigned Pvv = ~0u, Mv = 0;
-                int score = m, best = m + 1, firstc = 0, lastc = 0;
-#pragma unroll 4
-                for (int c = 0; c < ncol; c++) {
-                    myers_step<unsigned, true>(peq[(int)cw[c] << lNBs], Pvv, Mv, score, top);
-                    bool lt = score < best;
-                    best = lt ? score : best;
-                    firstc = lt ? c : firstc;
-                    lastc = (score == best) ? c : lastc;
-                }
-                if (best <= kidx) {
-                    if (use_slots)
-                        atomicMin(&bres[en.slot + bi], ((unsigned)best << 24) | ((unsigned)en.loc_ord << 16) |
-                                                           ((unsigned)(en.tj0 + firstc) << 8) | (unsigned)(en.tj0 + lastc));
-                    else   // barcode bi seen at distance `best` (any location): the lowest non-empty level wins
-                        atomicOr(&dmask[(((en.slot >> logG) * (kidx + 1)) + best) * MBW + (bi >> 5)], 1u << (bi & 31));
-                }
-            }
+            stamp(3);
+            phase3b_barcodes(nE);
             __syncthreads();
-            STAMP(4);
-
-            // 3c: per searched hit: best distance, tie set (ballot), tails extent.  Lanes = (hit, barcode slot):
-            // group-of-G reductions by xor-shuffles, the tie bitmask straight from the ballot.
-            if (!use_slots) {
-                // lean mode: best = lowest distance level with any barcode, tie set = that level's bitmask
-                for (int q = q0 + tid; q < q1; q += NT) {
-                    int item = queue[q];
-                    const unsigned *dm = dmask + (q - q0) * (kidx + 1) * MBW;
-                    for (int d = 0; d <= kidx; d++) {
-                        int nt = 0, first = -1;
-                        for (int w = 0; w < MBW; w++) {
-                            unsigned m = dm[d * MBW + w];
-                            if (m && first < 0) first = w * 32 + __ffs(m) - 1;
-                            nt += __popc(m);
-                        }
-                        if (nt) {
-                            HitL &hl = hits[item];
-                            hl.bbest = (signed char)d; hl.ntied = (short)nt; hl.first_tied = (short)first;
-                            for (int w = 0; w < MBW; w++) tiem[item * MBW + w] = dm[d * MBW + w];
-                            break;
-                        }
-                    }
-                    if constexpr (BSV == 3) {
-                        // --trim tails: max over the within-k barcodes of the last optimal end of the alignment the
-                        // reference keeps for each (its FIRST location at its best distance, match_one_end :806-811)
-                        HitL &hl = hits[item];
-                        if (hl.bbest >= 0) {
-                            const int ne = hl.nloc, e0 = offsA[item] - e_base;
-                            int t = -0x7FFFFFFF;
-                            if (ne == 1) t = etail[e0];
-                            else {
-                                const int dn = cmode ? (int)clist[item] : item;
-                                const int r = divH(dn), h = dn - __mul24(r, H), p = h >> 1, X = h & 1;
-                                const int base = end_geom(lensC[r], S).base, bsm = P->bs_m;
-                                const unsigned *reb = bsre + __mul24(p, T.BSP);   // MBW == 1 on this path
-                                unsigned GM[4], prev[4] = {0u, 0u, 0u, 0u}, lower = 0;
-#pragma unroll
-                                for (int d = 0; d < 4; d++) { GM[d] = d <= kidx ? (dm[d] & ~lower) : 0u; lower |= d <= kidx ? dm[d] : 0u; }
-                                for (int e = e0; e < e0 + ne; e++) {
-                                    const EntL en = ents[e];
-                                    if (!en.ok) continue;
-                                    unsigned want[4], seen[4], ML[4];
-#pragma unroll
-                                    for (int d = 0; d < 4; d++) want[d] = GM[d] & ~prev[d];
-                                    if (!(want[0] | want[1] | want[2] | want[3])) break;   // every barcode has its location
-                                    const unsigned char *cwt = codes + __mul24(r * 2 + X, CS) + en.tj0;
-                                    int tc = -1;
-                                    if (bsm == 13) bitsliced_shw_pad_tails<3, 13>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
-                                    else if (bsm <= 8 && bsm > 3) bitsliced_shw_pad_tails<3, 8>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
-                                    else if (bsm <= 12 && bsm > 3) bitsliced_shw_pad_tails<3, 12>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
-                                    else bitsliced_shw_pad_tails<3, 16>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
-                                    if (tc >= 0) { int v = (int)en.tj0 + tc + base - (int)en.delta; t = v > t ? v : t; }
-#pragma unroll
-                                    for (int d = 0; d < 4; d++) prev[d] |= ML[d] & GM[d];
-                                }
-                            }
-                            hl.tail_end = t;
-                        }
-                    }
-                }
-            } else if (G <= 64) {
-                const int nslots = (q1 - q0) << logG;
-                for (int base_i = wave * 64; base_i < nslots; base_i += NT) {
-                    const int i = base_i + (tid & 63);
-                    const bool in = i < nslots;
-                    const int q = q0 + ((in ? i : 0) >> logG), sl = i & (G - 1);
-                    const int item = queue[q];
-                    const int r = divH(item), h = item - __mul24(r, H), p = h >> 1;
-                    const int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
-                    const bool live = in && sl < nb;
-                    unsigned v = live ? bres[i] : 0xFFFFFFFFu;
-                    if (live && dbg_bdist)
-                        dbg_bdist[(size_t)r0 * H * maxB + (size_t)item * maxB + sl] = (v == 0xFFFFFFFFu) ? (int8_t)-1 : (int8_t)(v >> 24);
-                    const int L = lensC[r];
-                    const EndGeom g = end_geom(L, S);
-                    int last_abs = -0x7FFFFFFF;
-                    if (v != 0xFFFFFFFFu) {
-                        int delta = 0;
-                        if (L < S) {   // short read: the location's slice start may have wrapped (Q1)
-                            int je = nth_location(masks + (size_t)item * MW, MW, hits[item].jstar, (v >> 16) & 0xFF);
-                            delta = bc_geom(L, g.base, (je - g.j_lo) + g.shift + 1).delta;
-                        }
-                        last_abs = (int)(v & 0xFF) + g.base - delta;
-                    }
-                    unsigned dmin = v >> 24;
-                    int tail = last_abs;
-                    for (int d = 1; d < G; d <<= 1) {
-                        unsigned o = (unsigned)__shfl_xor((int)dmin, d, 64);
-                        int t = __shfl_xor(tail, d, 64);
-                        dmin = o < dmin ? o : dmin;
-                        tail = t > tail ? t : tail;
-                    }
-                    const bool tied = (v >> 24) == dmin && dmin != 255;
-                    unsigned long long bal = __ballot(tied);
-                    const int gshift = (tid & 63) & ~(G - 1);
-                    unsigned long long gm = (G == 64) ? bal : ((bal >> gshift) & ((1ull << G) - 1ull));
-                    int first = gm ? __ffsll((long long)gm) - 1 : 0;
-                    if (in && sl == 0 && dmin != 255) {
-                        HitL &hl = hits[item];
-                        hl.bbest = (signed char)dmin; hl.ntied = (short)__popcll(gm); hl.first_tied = (short)first;
-                        hl.tail_end = tail;
-                        tiem[item * MBW] = (unsigned)gm;
-                        if (MBW > 1) tiem[item * MBW + 1] = (unsigned)(gm >> 32);
-                    }
-                }
-            } else
-            for (int q = q0 + tid; q < q1; q += NT) {
-                int item = queue[q];
-                HitL &hl = hits[item];
-                int r = divH(item), h = item - __mul24(r, H), p = h >> 1;
-                int nb = LP.pbc_off[p + 1] - LP.pbc_off[p];
-                const unsigned *br = bres + ((q - q0) << logG);
-                unsigned best = 255;
-                for (int i = 0; i < nb; i++) { unsigned d = br[i] >> 24; best = d < best ? d : best; }
-                if (dbg_bdist)
-                    for (int i = 0; i < nb; i++)
-                        dbg_bdist[(size_t)r0 * H * maxB + (size_t)item * maxB + i] =
-                            (br[i] == 0xFFFFFFFFu) ? (int8_t)-1 : (int8_t)(br[i] >> 24);
-                if (best == 255) continue;
-                int L = lensC[r];
-                EndGeom g = end_geom(L, S);
-                int ntied = 0, first = -1, tail = -0x7FFFFFFF;
-                for (int i = 0; i < nb; i++) {
-                    unsigned v = br[i];
-                    if (v == 0xFFFFFFFFu) continue;
-                    int delta = 0;
-                    if (L < S) {   // short read: the location's slice start may have wrapped (Q1)
-                        int je = nth_location(masks + (size_t)item * MW, MW, hl.jstar, (v >> 16) & 0xFF);
-                        delta = bc_geom(L, g.base, (je - g.j_lo) + g.shift + 1).delta;
-                    }
-                    int last_abs = (int)(v & 0xFF) + g.base - delta;
-                    tail = last_abs > tail ? last_abs : tail;
-                    if ((v >> 24) == best) {
-                        if (ntied == 0) first = i;
-                        ntied++;
-                        tiem[item * MBW + (i >> 5)] |= 1u << (i & 31);
-                    }
-                }
-                hl.bbest = (signed char)best; hl.ntied = (short)ntied; hl.first_tied = (short)first;
-                hl.tail_end = tail;
-            }
+            stamp(4);
+            phase3c_summary(q0, q1, e_base);
             __syncthreads();
-            STAMP(5);
+            stamp(5);
             q0 = q1;
         }
-        }   // live
+    }
 
-        }   // have
+    __device__ __forceinline__ void zero_for_next() {
         // the encode target buffers: namask is OR-ed into, the next tile's orientation votes are counted up
         for (int i = tid; i < R * 2 * MW; i += NT) namask[i] = 0;
         for (int i = tid; i < R; i += NT) { ocnt[(par ^ 1) * R + i] = 0; rflag[(par ^ 1) * R + i] = 0; }
         if (live) for (int i = tid; i < nr * ncand; i += NT) cumL[i] = 0;   // (the masks / scan arrays it overlays are dead by now)
         if (tid == 0) { aggr[9] = (int)popped; aggr[11] = 0; }
         __syncthreads();
-        const uint32_t nxt = (uint32_t)aggr[9];
-        STAMP(0);
+        nxt = (uint32_t)aggr[9];
 
-        // ---- phase 4 || phase 1: the scorer of this tile (lowest wave(s), one lane per read) runs beside the
-        // load + encode of the next tile (all other waves; every wave while the pipeline fills)
-        if (live && wave < SW) {
-            unsigned long long t_sc0 = 0;
-            if (timing) t_sc0 = clock64();   // diagnostic: the scorer wave's own time inside the shared region
-            // G lanes per read while the tile is smaller than the wave (R <= 32: panels with many primers)
-            const int lG = R <= 16 ? 2 : (R <= 32 ? 1 : 0), G = 1 << lG;
-            const int r = tid >> lG, sub = tid & (G - 1);
-            if (r < nr) {
-                int L = lensC[r];
-                bool filtered = (minlen != -1 && L < minlen) || (maxlen != -1 && L > maxlen);
-                const unsigned long long pm_r = pmask[r];   // (the lanes sharing a read sit in one wave: all have read it
-                if (cfilt && sub == 0) pmask[r] = 0ull;     //  when the lead lane clears it for the next tile)
-                if (sub == 0) atomicAdd(&aggr[0], 1);
-                if (filtered) {
-                    if (sub == 0) {
-                        atomicAdd(&aggr[2], 1);
-                        smx_op op;
-                        op.sample = -1; op.trim_start = 0; op.trim_end = 0; op.pool = -1; op.p1 = op.p2 = -1; op.barcode = -1;
-                        op.dist[0] = op.dist[1] = op.dist[2] = op.dist[3] = -1;
-                        op.rtype = SMX_R_FILTERED; op.flags = 0; op.n_ops = 0; op.read = r0 + r;
-                        opsL[r] = op;
+    }
+
+    // ---- phase 4: the scorer of this tile (lowest wave(s), one lane per read)
+    __device__ __forceinline__ void phase4_score() {
+        unsigned long long t_sc0 = 0;
+        if (timing) t_sc0 = clock64();   // diagnostic: the scorer wave's own time inside the shared region
+        // G lanes per read while the tile is smaller than the wave (R <= 32: panels with many primers)
+        const int lG = R <= 16 ? 2 : (R <= 32 ? 1 : 0), G = 1 << lG;
+        const int r = tid >> lG, sub = tid & (G - 1);
+        if (r < nr) {
+            int L = lensC[r];
+            bool filtered = (minlen != -1 && L < minlen) || (maxlen != -1 && L > maxlen);
+            const unsigned long long pm_r = pmask[r];   // (the lanes sharing a read sit in one wave: all have read it
+            if (cfilt && sub == 0) pmask[r] = 0ull;     //  when the lead lane clears it for the next tile)
+            if (sub == 0) atomicAdd(&aggr[0], 1);
+            if (filtered) {
+                if (sub == 0) {
+                    atomicAdd(&aggr[2], 1);
+                    smx_op op;
+                    op.sample = -1; op.trim_start = 0; op.trim_end = 0; op.pool = -1; op.p1 = op.p2 = -1; op.barcode = -1;
+                    op.dist[0] = op.dist[1] = op.dist[2] = op.dist[3] = -1;
+                    op.rtype = SMX_R_FILTERED; op.flags = 0; op.n_ops = 0; op.read = r0 + r;
+                    opsL[r] = op;
+                }
+            } else {
+                ReadCtx c;
+                c.P = P; c.LP = LP; c.MBW = MBW; c.L = L; c.S = S;
+                c.trim = sp ? (int)SMX_TRIM_BARCODES : P->trim; c.derep = sp ? (int)SMX_DEREP_BEST : P->derep;
+                c.npair = NPAIR;
+                if (cmode) { c.hits = hits; c.tiem = tiem; c.hmap = hmap + r * H; }
+                else { c.hits = hits + r * H; c.tiem = tiem + r * H * MBW; c.hmap = nullptr; }
+                c.hcand = cfilt ? hcand : nullptr;
+                c.pm = pm_r;
+                c.g = end_geom(L, S);
+                int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
+                int ori = 3;
+                if (preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
+                c.set_live(ori);
+                Emitter E;
+                E.c = &c; E.primary = opsL + r; E.extra = extra; E.extra_cap = extra_cap;
+                E.n_extra = tile_counter + 3;   // see the kernel's epilogue
+                E.counts = counts; E.cum = cumL + r * ncand; E.aggr = aggr; E.read = r0 + r;
+                E.n = 0; E.matched = false; E.overflow = false;
+                const bool done = score_fast(E, ori, sub, G);
+                if (sub == 0) {
+                    if (!done) score_general(E, ori);
+                    opsL[r].n_ops = (uint16_t)E.n;
+                    if (E.matched) atomicAdd(&aggr[1], 1);
+                    if (E.n > 1) atomicAdd(&aggr[6], 1);
+                    if (E.overflow) atomicAdd(&aggr[7], 1);
+                }
+            }
+        }
+        if (timing) tacc[9] += clock64() - t_sc0;
+
+    }
+
+    // ---- phase 1 (of the NEXT tile, all other waves; every wave while the pipeline fills)
+    __device__ __forceinline__ void phase1_encode() {
+        // ---- phase 1 (of the NEXT tile): windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
+        const int wid = live ? tid - 64 * SW : tid, nw = live ? NT - 64 * SW : NT;
+        const bool timing_enc = dbg_phase != nullptr && tid == 64 * SW;   // diagnostic: this wave's own encode time
+        unsigned long long t_enc0 = 0;
+        if (timing_enc) t_enc0 = clock64();
+        uint32_t r0n;
+        int nrn;
+        tile_span(nxt, r0n, nrn);
+        int *lensN = lensL + (par ^ 1) * R;
+        if (wid < nrn) lensN[wid] = lens[r0n + wid];
+        // one 16-byte chunk: generic per-byte encode (short reads, search_len not a multiple of 16)
+        auto encode_bytes = [&](int r, int L, int cpos, const uint4 &v) {
+            int Sp = L < S ? L : S;
+            unsigned w[4] = {v.x, v.y, v.z, v.w};
+            unsigned char *rowA = codes + (r * 2 + 0) * CS, *rowB = codes + (r * 2 + 1) * CS;
+            for (int b = 0; b < 16; b++) {
+                int pos = cpos + b;
+                unsigned ch = (w[b >> 2] >> ((b & 3) * 8)) & 0xFF;
+                if (pos < S) {            // head byte i -> A[Sp-1-i] = code(complement)
+                    if (pos < Sp) {
+                        unsigned cd = lut[256 + ch];
+                        int j = Sp - 1 - pos;
+                        rowA[j] = (unsigned char)cd;
+                        if (cd > 3) { atomicOr(&namask[(r * 2 + 0) * MW + (j >> 5)], 1u << (j & 31)); rflag[(par ^ 1) * R + r] = 1; }
                     }
-                } else {
-                    ReadCtx c;
-                    c.P = P; c.LP = LP; c.MBW = MBW; c.L = L; c.S = S;
-                    c.trim = sp ? (int)SMX_TRIM_BARCODES : P->trim; c.derep = sp ? (int)SMX_DEREP_BEST : P->derep;
-                    c.npair = NPAIR;
-                    if (cmode) { c.hits = hits; c.tiem = tiem; c.hmap = hmap + r * H; }
-                    else { c.hits = hits + r * H; c.tiem = tiem + r * H * MBW; c.hmap = nullptr; }
-                    c.hcand = cfilt ? hcand : nullptr;
-                    c.pm = pm_r;
-                    c.g = end_geom(L, S);
-                    int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
-                    int ori = 3;
-                    if (preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
-                    c.set_live(ori);
-                    Emitter E;
-                    E.c = &c; E.primary = opsL + r; E.extra = extra; E.extra_cap = extra_cap;
-                    E.n_extra = tile_counter + 3;   // see the kernel's epilogue
-                    E.counts = counts; E.cum = cumL + r * ncand; E.aggr = aggr; E.read = r0 + r;
-                    E.n = 0; E.matched = false; E.overflow = false;
-                    const bool done = score_fast(E, ori, sub, G);
-                    if (sub == 0) {
-                        if (!done) score_general(E, ori);
-                        opsL[r].n_ops = (uint16_t)E.n;
-                        if (E.matched) atomicAdd(&aggr[1], 1);
-                        if (E.n > 1) atomicAdd(&aggr[6], 1);
-                        if (E.overflow) atomicAdd(&aggr[7], 1);
+                } else if (pos < 2 * S) { // tail byte j -> B[j]
+                    int j = pos - S;
+                    if (j < Sp) {
+                        unsigned cd = lut[ch];
+                        rowB[j] = (unsigned char)cd;
+                        if (cd > 3) { atomicOr(&namask[(r * 2 + 1) * MW + (j >> 5)], 1u << (j & 31)); rflag[(par ^ 1) * R + r] = 1; }
                     }
                 }
             }
-            if (timing) tacc[9] += clock64() - t_sc0;
-        } else if (nxt < n_tiles) {
-            // ---- phase 1 (of the NEXT tile): windows -> codes.  16-byte coalesced loads; A = revcomp of the head window.
-            const int wid = live ? tid - 64 * SW : tid, nw = live ? NT - 64 * SW : NT;
-            const bool timing_enc = dbg_phase != nullptr && tid == 64 * SW;   // diagnostic: this wave's own encode time
-            unsigned long long t_enc0 = 0;
-            if (timing_enc) t_enc0 = clock64();
-            uint32_t r0n;
-            int nrn;
-            tile_span(nxt, r0n, nrn);
-            int *lensN = lensL + (par ^ 1) * R;
-            if (wid < nrn) lensN[wid] = lens[r0n + wid];
-            // one 16-byte chunk: generic per-byte encode (short reads, search_len not a multiple of 16)
-            auto encode_bytes = [&](int r, int L, int cpos, const uint4 &v) {
-                int Sp = L < S ? L : S;
-                unsigned w[4] = {v.x, v.y, v.z, v.w};
-                unsigned char *rowA = codes + (r * 2 + 0) * CS, *rowB = codes + (r * 2 + 1) * CS;
-                for (int b = 0; b < 16; b++) {
-                    int pos = cpos + b;
-                    unsigned ch = (w[b >> 2] >> ((b & 3) * 8)) & 0xFF;
-                    if (pos < S) {            // head byte i -> A[Sp-1-i] = code(complement)
-                        if (pos < Sp) {
-                            unsigned cd = lut[256 + ch];
-                            int j = Sp - 1 - pos;
-                            rowA[j] = (unsigned char)cd;
-                            if (cd > 3) { atomicOr(&namask[(r * 2 + 0) * MW + (j >> 5)], 1u << (j & 31)); rflag[(par ^ 1) * R + r] = 1; }
-                        }
-                    } else if (pos < 2 * S) { // tail byte j -> B[j]
-                        int j = pos - S;
-                        if (j < Sp) {
-                            unsigned cd = lut[ch];
-                            rowB[j] = (unsigned char)cd;
-                            if (cd > 3) { atomicOr(&namask[(r * 2 + 1) * MW + (j >> 5)], 1u << (j & 31)); rflag[(par ^ 1) * R + r] = 1; }
-                        }
-                    }
-                }
-            };
-            // (the default-flags kernels are only launched behind the prescan: their ASCII fast path is compiled out)
-            if ((S & 15) == 0 && (sp || aux.codes2 != nullptr)) {
-                // behind the prescan: the transpose kernel has already turned every pure-ACGT window into 2-bit codes, row-major
-                // per read and in DP order (end A reverse-complemented): one dword per (read, end, 16-column chunk), the tile's
-                // dwords contiguous.  Four shift/mask/swap steps spell the dword out as 16 code bytes.  Reads the transpose kernel
-                // flagged (a window with anything but upper-case ACGT) and reads shorter than the window take the ASCII path.
-                const int hc = S >> 4, per = 2 * hc;
-                const unsigned *c2 = aux.codes2 + (size_t)r0n * per;
-                const unsigned permagic = (unsigned)((0x100000000ull + (unsigned)per - 1) / (unsigned)per);
-                for (int ci = wid; ci < nrn * per; ci += nw) {
-                    const unsigned z = c2[ci];
-                    const int r = (int)__umulhi((unsigned)ci, permagic), rem = ci - __mul24(r, per);
-                    const int end = rem >= hc ? 1 : 0, c = rem - (end ? hc : 0);
-                    const unsigned flagged = aux.naflag[r0n + r];   // 1: shorter than the window, or not pure upper-case ACGT
-                    if (!flagged) {
-                        unsigned *dst = (unsigned *)(codes + __mul24(r * 2 + end, CS)) + 4 * c;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const unsigned x = (z >> (2 * q)) & 0x03030303u;       // A 0, C 1, T 2, G 3 ...
-                            dst[q] = x ^ ((x >> 1) & 0x01010101u);               // ... -> the kernels' A 0, C 1, G 2, T 3
-                        }
-                    } else {   // the same 16 window bytes from the ASCII buffer (any 16-byte piece of that end: all get visited)
-                        const uint4 v = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (end ? S : 0) + 16 * c);
-                        encode_bytes(r, lens[r0n + r], (end ? S : 0) + 16 * c, v);
-                    }
-                }
-            } else if (!sp && (S & 15) == 0) {
-                // fast path: chunks never straddle the head/tail boundary; items are ordered [all head chunks]
-                // [all tail chunks] so that a wave is (almost always) uniform in role.  Full windows (len >= S):
-                // four LUT lookups -> one packed dword store; the head is written reversed (reverse complement).
-                const int hc = S >> 4, nhead = nrn * hc, S4 = S >> 2;
-                for (int ci = wid; ci < 2 * nhead; ci += nw) {
-                    const bool tail = ci >= nhead;
-                    const int k = tail ? ci - nhead : ci;
-                    const int r = (int)__umulhi((unsigned)k, hcmagic), c = k - __mul24(r, hc);
-                    const uint4 v = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (tail ? S : 0) + 16 * c);
-                    const int L = lens[r0n + r];
-                    // ACGT fast path, four bases per dword without the LUT: (ch >> 1) & 3 maps A,C,T,G -> 0,1,2,3; swapping 2 and 3
-                    // gives the code, xor 3 the complement's code; one v_perm rebuilds the four letters from the codes and a
-                    // compare proves that the dword held nothing but upper-case ACGT (anything else: per-byte LUT path below)
-                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
-                    unsigned pk[4];
-                    bool acgt = L >= S;
+        };
+        // (the default-flags kernels are only launched behind the prescan: their ASCII fast path is compiled out)
+        if ((S & 15) == 0 && (sp || aux.codes2 != nullptr)) {
+            // behind the prescan: the transpose kernel has already turned every pure-ACGT window into 2-bit codes, row-major
+            // per read and in DP order (end A reverse-complemented): one dword per (read, end, 16-column chunk), the tile's
+            // dwords contiguous.  Four shift/mask/swap steps spell the dword out as 16 code bytes.  Reads the transpose kernel
+            // flagged (a window with anything but upper-case ACGT) and reads shorter than the window take the ASCII path.
+            const int hc = S >> 4, per = 2 * hc;
+            const unsigned *c2 = aux.codes2 + (size_t)r0n * per;
+            const unsigned permagic = (unsigned)((0x100000000ull + (unsigned)per - 1) / (unsigned)per);
+            for (int ci = wid; ci < nrn * per; ci += nw) {
+                const unsigned z = c2[ci];
+                const int r = (int)__umulhi((unsigned)ci, permagic), rem = ci - __mul24(r, per);
+                const int end = rem >= hc ? 1 : 0, c = rem - (end ? hc : 0);
+                const unsigned flagged = aux.naflag[r0n + r];   // 1: shorter than the window, or not pure upper-case ACGT
+                if (!flagged) {
+                    unsigned *dst = (unsigned *)(codes + __mul24(r * 2 + end, CS)) + 4 * c;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const unsigned x = (w[q] >> 1) & 0x03030303u;
-                        const unsigned y = x ^ ((x >> 1) & 0x01010101u);
-                        acgt = acgt && (__builtin_amdgcn_perm(0u, 0x54474341u, y) == w[q]);
-                        pk[q] = tail ? y : __builtin_amdgcn_perm(0u, y ^ 0x03030303u, 0x00010203u);
+                        const unsigned x = (z >> (2 * q)) & 0x03030303u;       // A 0, C 1, T 2, G 3 ...
+                        dst[q] = x ^ ((x >> 1) & 0x01010101u);               // ... -> the kernels' A 0, C 1, G 2, T 3
                     }
-                    if (acgt) {
-                        unsigned *dst = (unsigned *)(codes + __mul24(r * 2 + (tail ? 1 : 0), CS));
-#pragma unroll
-                        for (int q = 0; q < 4; q++) dst[tail ? 4 * c + q : S4 - 1 - (4 * c + q)] = pk[q];
-                    } else {
-                        encode_bytes(r, L, (tail ? S : 0) + 16 * c, v);
-                    }
-                }
-            } else if (!sp) {
-                const int chunks = stride / 16;
-                const uint4 *src = (const uint4 *)(windows + (size_t)r0n * stride);
-                for (int ci = wid; ci < nrn * chunks; ci += nw) {
-                    int r = ci / chunks;
-                    encode_bytes(r, lens[r0n + r], (ci - r * chunks) * 16, src[ci]);
+                } else {   // the same 16 window bytes from the ASCII buffer (any 16-byte piece of that end: all get visited)
+                    const uint4 v = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (end ? S : 0) + 16 * c);
+                    encode_bytes(r, lens[r0n + r], (end ? S : 0) + 16 * c, v);
                 }
             }
-            if (timing_enc) tacc[8] += clock64() - t_enc0;
+        } else if (!sp && (S & 15) == 0) {
+            // fast path: chunks never straddle the head/tail boundary; items are ordered [all head chunks]
+            // [all tail chunks] so that a wave is (almost always) uniform in role.  Full windows (len >= S):
+            // four LUT lookups -> one packed dword store; the head is written reversed (reverse complement).
+            const int hc = S >> 4, nhead = nrn * hc, S4 = S >> 2;
+            for (int ci = wid; ci < 2 * nhead; ci += nw) {
+                const bool tail = ci >= nhead;
+                const int k = tail ? ci - nhead : ci;
+                const int r = (int)__umulhi((unsigned)k, hcmagic), c = k - __mul24(r, hc);
+                const uint4 v = *(const uint4 *)(windows + (size_t)(r0n + r) * stride + (tail ? S : 0) + 16 * c);
+                const int L = lens[r0n + r];
+                // ACGT fast path, four bases per dword without the LUT: (ch >> 1) & 3 maps A,C,T,G -> 0,1,2,3; swapping 2 and 3
+                // gives the code, xor 3 the complement's code; one v_perm rebuilds the four letters from the codes and a
+                // compare proves that the dword held nothing but upper-case ACGT (anything else: per-byte LUT path below)
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                unsigned pk[4];
+                bool acgt = L >= S;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned x = (w[q] >> 1) & 0x03030303u;
+                    const unsigned y = x ^ ((x >> 1) & 0x01010101u);
+                    acgt = acgt && (__builtin_amdgcn_perm(0u, 0x54474341u, y) == w[q]);
+                    pk[q] = tail ? y : __builtin_amdgcn_perm(0u, y ^ 0x03030303u, 0x00010203u);
+                }
+                if (acgt) {
+                    unsigned *dst = (unsigned *)(codes + __mul24(r * 2 + (tail ? 1 : 0), CS));
+#pragma unroll
+                    for (int q = 0; q < 4; q++) dst[tail ? 4 * c + q : S4 - 1 - (4 * c + q)] = pk[q];
+                } else {
+                    encode_bytes(r, L, (tail ? S : 0) + 16 * c, v);
+                }
+            }
+        } else if (!sp) {
+            const int chunks = stride / 16;
+            const uint4 *src = (const uint4 *)(windows + (size_t)r0n * stride);
+            for (int ci = wid; ci < nrn * chunks; ci += nw) {
+                int r = ci / chunks;
+                encode_bytes(r, lens[r0n + r], (ci - r * chunks) * 16, src[ci]);
+            }
         }
-        __syncthreads();
-        STAMP(6);
+        if (timing_enc) tacc[8] += clock64() - t_enc0;
+    }
+
+    __device__ __forceinline__ void phase5_store() {
         // result records: LDS -> HBM, 16 bytes per lane, fully coalesced
         if (live) {
             const uint4 *srcv = (const uint4 *)opsL;
@@ -2068,22 +2126,95 @@ __global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t
             }
         }
         if (dbg_hits) __syncthreads();   // the dump reads hits[]; the next tile's primer scan rewrites them
-        STAMP(7);
-        if (nxt >= n_tiles) break;   // nothing was encoded: the queue is drained
-        cur = nxt;
-        par ^= 1;
-        // (no barrier needed here: the next writers of hits / masks / opsL come after the barriers of phase 2)
+
     }
-    if (timing)
-        for (int i = 0; i < 10; i++) dbg_phase[(size_t)blockIdx.x * 16 + i] += tacc[i];
-    if (timing) dbg_phase[(size_t)blockIdx.x * 16 + 14] += tacc[0] != 0 || tacc[1] != 0 ? 1 : 0;   // did this workgroup get any tile?
-    if (dbg_phase != nullptr && (tid & 63) == 0)   // placement of this wave: HW_ID (simd, wave slot, cu, se)
-        dbg_phase[(size_t)blockIdx.x * 16 + 10 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
-#undef STAMP
-    // block aggregates -> global counters
-    if (tid < 8 && aggr[tid]) atomicAdd(&counts[tid], (unsigned long long)aggr[tid]);
-    __syncthreads();
-    if (tid == 0) workgroup_done();
+
+    // dynamic tile queue: workgroups pull tiles from a global counter (zeroed on the stream before the
+    // launch), so the tail is one tile long whatever the residency turns out to be
+    // Software pipeline over tiles: while the lowest wave(s) run the scorer of tile t (one lane per read), the other
+    // waves load and encode tile t+1.  codes / namask are dead by then; lens and the orientation votes are double-buffered.
+    __device__ __forceinline__ void run() {
+        cur = 0xFFFFFFFFu;                // tile being processed (none yet)
+        par = 1;                          // cur's lens/ocnt buffer; the tile being encoded uses par ^ 1
+        for (;;) {
+            // keep per-thread address arithmetic inside the tile body: hoisted out of this loop it lives in VGPRs across
+            // every phase and ends up spilled to scratch (HBM traffic, reload latency); recomputing it is a few ALU ops
+            asm volatile("" : "+v"(tid));
+            const bool have = cur != 0xFFFFFFFFu;
+            // the tile to encode during this iteration: the queue pop is issued here, its result is only parked in LDS after
+            // the barcode phases (a returning global atomic takes microseconds; storing it at once stalled wave 0, and with
+            // it the first barrier of every tile)
+            popped = 0;
+            if (tid == 0) popped = atomicAdd(tile_counter, 1u);
+            r0 = 0u;
+            nr = 0;
+            if (have) tile_span(cur, r0, nr);
+            nh = nr * H;
+            nI = nh;          // alignments with a record: all of them, or (compact mode) the flagged ones
+            live = have;
+            lensC = lensL + par * R; ocntC = ocnt + par * R;
+            rflagC = rflag + par * R;
+            if (timing) tacc[10] = clock64();
+            if (have) {
+                phase2_primers();
+                stamp(1);
+                if (live) {
+                    phase3a_entries();
+                    stamp(2);
+                    phase3_rounds();
+                }
+            }
+            zero_for_next();
+            stamp(0);
+            // ---- phase 4 || phase 1: the scorer of this tile (lowest wave(s), one lane per read) runs beside the
+            // load + encode of the next tile (all other waves; every wave while the pipeline fills)
+            if (live && wave < SW) phase4_score();
+            else if (nxt < n_tiles) phase1_encode();
+            __syncthreads();
+            stamp(6);
+            phase5_store();
+            stamp(7);
+            if (nxt >= n_tiles) break;   // nothing was encoded: the queue is drained
+            cur = nxt;
+            par ^= 1;
+            // (no barrier needed here: the next writers of hits / masks / opsL come after the barriers of phase 2)
+        }
+    }
+
+    __device__ __forceinline__ void finish() {
+        if (timing)
+            for (int i = 0; i < 10; i++) dbg_phase[(size_t)blockIdx.x * 16 + i] += tacc[i];
+        if (timing) dbg_phase[(size_t)blockIdx.x * 16 + 14] += tacc[0] != 0 || tacc[1] != 0 ? 1 : 0;   // did this workgroup get any tile?
+        if (dbg_phase != nullptr && (tid & 63) == 0)   // placement of this wave: HW_ID (simd, wave slot, cu, se)
+            dbg_phase[(size_t)blockIdx.x * 16 + 10 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+    #undef STAMP
+        // block aggregates -> global counters
+        if (tid < 8 && aggr[tid]) atomicAdd(&counts[tid], (unsigned long long)aggr[tid]);
+        __syncthreads();
+        if (tid == 0) workgroup_done();
+
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// BSV selects the barcode scan compiled into the kernel: see the comment in front of DemuxTile's template parameters above.
+template <typename PW, int NT, int BSV, int CM = 0, int SP = 0>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
+__global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
+                                                    const int32_t *__restrict__ lens, uint32_t n_reads, int R_arg,
+                                                    smx_op *__restrict__ ops, smx_op *__restrict__ extra,
+                                                    uint32_t extra_cap, uint32_t *n_extra,
+                                                    unsigned long long *counts, smx_hit *dbg_hits, int8_t *dbg_bdist_arg,
+                                                    unsigned *tile_counter, int use_slots_arg,
+                                                    const unsigned *__restrict__ pre, uint32_t npad, DemuxAux aux) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    (void)npad;
+    DemuxTile<PW, NT, BSV, CM, SP> D;
+    if (!D.setup(lds, &Pv, windows, lens, n_reads, R_arg, ops, extra, extra_cap, n_extra, counts, dbg_hits, dbg_bdist_arg,
+                 tile_counter, use_slots_arg, pre, aux))
+        return;
+    D.stage_panel();
+    D.run();
+    D.finish();
 }
 
 #if SMX_PART == 1

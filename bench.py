@@ -283,50 +283,83 @@ def build_compiled_panel(pf, sf, config, trim=None, cli_args=""):
 
 
 class DeviceBatches:
-    """N resident input batches of one shape + one set of output buffers; step(i) runs the hot path on batch i % N."""
+    """N resident input batches of one shape, and one set of output buffers per HIP stream; step(i) runs the hot path on
+    batch i % N, on stream i % n_streams (round robin: what a caller with several batches in flight does -- the product's
+    lanes are that caller)."""
 
-    def __init__(self, lib, cp, read_sets, dev, stream):
+    def __init__(self, lib, cp, read_sets, dev, streams):
         import torch
         from specimux_amd import _lib
-        self.lib, self.cp, self._lib, self.stream = lib, cp, _lib, stream
+        self.lib, self.cp, self._lib = lib, cp, _lib
+        self.streams = list(streams) if isinstance(streams, (list, tuple)) else [streams]
+        self.stream = self.streams[0]
         self.n = len(read_sets[0].lens)
         assert all(len(r.lens) == self.n for r in read_sets)
         self.windows = [torch.from_numpy(r.windows(cp.window_stride)).to(dev) for r in read_sets]
         self.lens = [torch.from_numpy(r.lens).to(dev) for r in read_sets]
-        self.ops = torch.empty(self.n * 32, dtype=torch.uint8, device=dev)
         self.extra_cap = self.n
-        self.extra = torch.empty(self.extra_cap * 32, dtype=torch.uint8, device=dev)
-        self.nextra = torch.zeros(4, dtype=torch.int32, device=dev)
-        self.counts = torch.zeros(cp.counts_len, dtype=torch.int64, device=dev)
+        self.out = [dict(ops=torch.empty(self.n * 32, dtype=torch.uint8, device=dev),
+                         extra=torch.empty(self.extra_cap * 32, dtype=torch.uint8, device=dev),
+                         nextra=torch.zeros(4, dtype=torch.int32, device=dev),
+                         counts=torch.zeros(cp.counts_len, dtype=torch.int64, device=dev)) for _ in self.streams]
+        self.counts = self.out[0]["counts"]
+        self.nextra = self.out[0]["nextra"]
+        torch.cuda.synchronize()
 
-    def step(self, i=0):
+    def step(self, i=0, n_streams=None):
         b = i % len(self.windows)
+        k = i % (n_streams or len(self.streams))
+        o, st = self.out[k], self.streams[k]
         self._lib.check(self.lib.smx_batch_run_device(
-            self.cp.handle, C.c_void_p(self.stream.cuda_stream), C.c_void_p(self.windows[b].data_ptr()),
-            C.c_void_p(self.lens[b].data_ptr()), self.n, C.c_void_p(self.ops.data_ptr()), C.c_void_p(self.extra.data_ptr()),
-            self.extra_cap, C.c_void_p(self.nextra.data_ptr()), C.c_void_p(self.counts.data_ptr()), None, None))
+            self.cp.handle, C.c_void_p(st.cuda_stream), C.c_void_p(self.windows[b].data_ptr()),
+            C.c_void_p(self.lens[b].data_ptr()), self.n, C.c_void_p(o["ops"].data_ptr()), C.c_void_p(o["extra"].data_ptr()),
+            self.extra_cap, C.c_void_p(o["nextra"].data_ptr()), C.c_void_p(o["counts"].data_ptr()), None, None))
+
+    def zero_counts(self):
+        for o in self.out:
+            o["counts"].zero_()
+
+    def total_counts(self):
+        """Sum of the per-stream counts vectors, left in stream 0's buffer (what the all-reduce then sums over the ranks)."""
+        import torch
+        torch.cuda.synchronize()
+        for o in self.out[1:]:
+            self.out[0]["counts"] += o["counts"]
+            o["counts"].zero_()
+        return self.out[0]["counts"]
+
+    def max_extra(self):
+        return max(int(o["nextra"][0].item()) for o in self.out)
 
     def kernel_times(self, reps=6):
-        """Mean device time of the three kernels of a step (HIP events on the launch stream), rotating like the timed loop."""
+        """Mean device time of the three kernels of a step (HIP events on the launch stream), one batch at a time on one
+        stream with the launches at their full size, rotating over the resident batches like the timed loop."""
+        import torch
+        torch.cuda.synchronize()
+        self.cp.set_streams(1)
         kms = np.zeros((reps, 3), dtype=np.float32)
         self._lib.check(self.lib.smx_debug_kernel_times(self.cp.handle, 1, None))
         for i in range(reps):
-            self.step(i)
+            self.step(i, 1)
             self._lib.check(self.lib.smx_debug_kernel_times(self.cp.handle, 1, kms[i].ctypes.data_as(C.POINTER(C.c_float))))
         self._lib.check(self.lib.smx_debug_kernel_times(self.cp.handle, 0, None))
+        self.cp.set_streams(len(self.streams))
         return tuple(float(x) for x in kms.mean(axis=0))
 
-    def event_timed(self, steps, rotate=True):
-        """ms per step over `steps` launches bracketed by events on the launch stream (after the headline region)."""
+    def event_timed(self, steps, rotate=True, n_streams=1):
+        """ms per step over `steps` launches (after the headline region): wall clock between two device synchronisations."""
         import torch
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.cp.set_streams(n_streams)
+        for i in range(2):
+            self.step(i if rotate else 0, n_streams)
         torch.cuda.synchronize()
-        e0.record(self.stream)
+        t0 = time.perf_counter()
         for i in range(steps):
-            self.step(i if rotate else 0)
-        e1.record(self.stream)
+            self.step(i if rotate else 0, n_streams)
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / steps
+        dt = time.perf_counter() - t0
+        self.cp.set_streams(len(self.streams))
+        return dt / steps * 1e3
 
 
 def step_kernel_list(k_t, k_d, k_b, demux_name):
@@ -349,7 +382,7 @@ def side_config(lib, config, dev, stream, tmp, n_reads=1_000_000, steps=10):
         db.step(i)
     ms = db.event_timed(steps)
     counts = db.counts.cpu().numpy().astype(np.uint64)
-    assert counts[_lib.CNT_TOTAL] == n_reads * (steps + 3) and counts[_lib.CNT_OVERFLOW] == 0
+    assert counts[_lib.CNT_TOTAL] == n_reads * (steps + 5) and counts[_lib.CNT_OVERFLOW] == 0
     k_t, k_d, k_b = db.kernel_times(4)
     bpr = (2 * 160 + 4 + 32) if config == "c5" else BYTES_PER_READ
     kernels_ms = k_t + k_d + k_b
@@ -403,6 +436,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)   # skip other_configs / pcie_inclusive / end_to_end (profiling runs)
     ap.add_argument("--e2e-reads", type=int, default=N_READS, help=argparse.SUPPRESS)
     ap.add_argument("--rotate", type=int, default=N_ROTATE, help=argparse.SUPPRESS)   # resident input batches (1: relaunch in place)
+    ap.add_argument("--streams", type=int, default=None, help=argparse.SUPPRESS)      # batches in flight (default: 2 on configs[1], else 1)
     ap.add_argument("--trim", default=None, help=argparse.SUPPRESS)   # e.g. tails: not the headline flags, DESIGN.md side numbers
     ap.add_argument("--cli-args", default="", help=argparse.SUPPRESS)  # extra specimux flags for side measurements, e.g. "-e 4"
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"], help=argparse.SUPPRESS)   # c3: 3072 specimens / 4 pools; c5: + 160-nt windows, 15 % errors
@@ -454,7 +488,14 @@ def main():
 
     n = a.reads
     stream = torch.cuda.current_stream()
-    db = DeviceBatches(lib, cp, sets, dev, stream)
+    # Batches in flight: the timed loop hands the steps round robin to n_streams HIP streams (smx_batch_run_device takes the
+    # stream; smx_panel_set_streams sizes each persistent demux launch to its share of the CUs), so that the next batch's
+    # memory-bound transpose and VALU-bound DP kernels run beside this batch's latency-bound demux kernel.  Measured on
+    # configs[1]: two streams +7 % over one; on the 8-primer panel nothing (its DP and compact demux kernels already fill the CUs).
+    n_streams = a.streams if a.streams else (2 if a.config == "c2" else 1)
+    streams = [stream] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
+    db = DeviceBatches(lib, cp, sets, dev, streams)
+    cp.set_streams(n_streams)
     d_counts = db.counts
 
     from specimux_amd.distributed import CountsReducer
@@ -470,15 +511,13 @@ def main():
     if world > 1:   # warm-up of the exchange too: the first collective on a fresh communicator sets up its rings
         reducer.allreduce_(torch.zeros_like(d_counts), stream.cuda_stream)
     torch.cuda.synchronize()
-    d_counts.zero_()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    db.zero_counts()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i, (s0, s1) in enumerate(ev):
-        s0.record(stream)
+    for i in range(a.steps):
         db.step(i)
-        s1.record(stream)
+    d_counts = db.total_counts()                       # (waits for every stream; adds the per-stream counts vectors)
     reducer.allreduce_(d_counts, stream.cuda_stream)   # the one exchange of the path: counts, once per job
     torch.cuda.synchronize()
     barrier()
@@ -487,12 +526,11 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    step_ms = [s0.elapsed_time(s1) for s0, s1 in ev]
 
     counts = d_counts.cpu().numpy().astype(np.uint64)
     total_reads = world * n * a.steps
     assert counts[_lib.CNT_TOTAL] == total_reads, (counts[:8], total_reads)
-    assert counts[_lib.CNT_OVERFLOW] == 0 and int(db.nextra[0].item()) <= db.extra_cap
+    assert counts[_lib.CNT_OVERFLOW] == 0 and db.max_extra() <= db.extra_cap
     n_rccl_ranks = world if (world > 1 and reducer.backend == "rccl") else (1 if world == 1 else 0)
     reducer.close()
     if world > 1:
@@ -502,7 +540,8 @@ def main():
 
     # ---- after the timed region (rank 0): the same launches on ONE batch relaunched in place (Infinity-Cache assisted),
     # per-kernel device times (HIP events on the launch stream)
-    single_ms = db.event_timed(a.steps, rotate=False) if len(sets) > 1 else None
+    one_stream_ms = db.event_timed(a.steps, rotate=True, n_streams=1)
+    single_ms = db.event_timed(a.steps, rotate=False, n_streams=1) if len(sets) > 1 else None
     k_t, k_d, k_b = db.kernel_times()
     bsv = 1 if parameters.max_dist_index < 4 and (a.trim or "") != "tails" else (3 if parameters.max_dist_index < 4 else 2)
     # (template arguments after the scan variant -- compact / redo mode, default-flags specialisation -- are chosen by the
@@ -510,10 +549,10 @@ def main():
     demux_name = f"smx::demux_kernel<unsigned int, 256, {bsv}, ...>"
     kernels_ms = k_t + k_d + k_b
 
-    avg_ms = float(np.mean(step_ms))
     bytes_per_read = (2 * 160 + 4 + 32) if a.config == "c5" else BYTES_PER_READ
-    achieved = bytes_per_read * n / (kernels_ms * 1e-3) / 1e9           # all kernels of a step: the scope of `value`
-    dom_achieved = bytes_per_read * n / (k_b * 1e-3) / 1e9              # the demux kernel alone
+    step_ms_value = elapsed / a.steps * 1e3 / 1.0                       # per step of THIS rank: the scope of `value`
+    achieved = bytes_per_read * n / (step_ms_value * 1e-3) / 1e9        # algorithmic bytes over the measured time per step
+    dom_achieved = bytes_per_read * n / (k_b * 1e-3) / 1e9              # the demux kernel alone, launched by itself
     traffic = None
     valu = None
     prof_name = "r03_pmc_summary.json" if os.path.exists(os.path.join(REPO, "profiles", "r03_pmc_summary.json")) else "r02_pmc_summary.json"
@@ -522,7 +561,7 @@ def main():
         traffic = prof.get("hbm_bytes_per_step")
         insts = prof.get("valu_instr_per_step")
         if insts:
-            ach = insts / (kernels_ms * 1e-3)
+            ach = insts / (step_ms_value * 1e-3)
             valu = {"bound": "valu-issue", "achieved": ach, "unit": "wave64 VALU instr/s", "instr_per_step": insts,
                     "instr_by_kernel": prof.get("valu_instr_by_kernel"),
                     "peak": VALU_PEAK_GUIDE, "frac": ach / VALU_PEAK_GUIDE,
@@ -530,7 +569,7 @@ def main():
                     "measured_mix_peak": VALU_PEAK_MEASURED_MIX, "frac_of_measured_mix": ach / VALU_PEAK_MEASURED_MIX,
                     "measured_mix_note": "tools/ubench/issue_rate.hip: 2.55-2.97 cycles per v_and/v_bitop3 at 4 waves per SIMD",
                     "source": f"instruction counts replayed from profiles/{prof_name} (rocprofv3 SQ_INSTS_VALU of this "
-                              "workload), not measured in this run; time = this run's HIP events"}
+                              "workload), not measured in this run; time = this run's measured time per step"}
     matched = counts[_lib.CNT_MATCHED] / total_reads
     out = {
         "metric": "reads/sec demultiplexed, 768-specimen ITS panel on 765k ONT-style reads",
@@ -544,19 +583,23 @@ def main():
                                 if a.config == "c3" else "configs[4]-style: the 3072-specimen panel, 15 % error reads, -l 160"),
                    "reads_per_gpu_per_step": n, "seed": SEED, "parallelism": f"read-sharded x{world}",
                    "rccl_ranks": n_rccl_ranks, "matched_fraction": float(matched),
-                   "resident_batches": len(sets),
+                   "resident_batches": len(sets), "streams": n_streams,
                    "scope": f"kernel-resident: end windows already in HBM, records left in HBM; the timed loop rotates over "
-                            f"{len(sets)} distinct resident batches ({len(sets) * n * cp.window_stride / 1e6:.0f} MB of windows)"},
+                            f"{len(sets)} distinct resident batches ({len(sets) * n * cp.window_stride / 1e6:.0f} MB of windows) and hands "
+                            f"the steps round robin to {n_streams} HIP stream(s)"},
         "step_kernels": step_kernel_list(k_t, k_d, k_b, demux_name),
-        "step_ms_events": {"avg": avg_ms, "min": float(np.min(step_ms))},
+        "step_kernels_note": "each kernel launched by itself at full size on one stream (HIP events on that stream)",
+        "one_stream": {"value": n / (one_stream_ms * 1e-3), "unit": "reads/s", "ms_per_step": one_stream_ms,
+                       "note": "the same rotation with one batch in flight at a time"},
         "single_buffer": ({"value": n / (single_ms * 1e-3), "unit": "reads/s", "ms_per_step": single_ms,
-                           "note": "one resident batch relaunched in place (inputs + intermediates fit the 256 MiB Infinity Cache): "
-                                   "NOT the headline"} if single_ms else None),
+                           "note": "one stream, one resident batch relaunched in place (inputs + intermediates fit the 256 MiB "
+                                   "Infinity Cache): NOT the headline"} if single_ms else None),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": (f"profiles/{prof_name} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE over the three kernels "
                                         "of a step; replayed, not measured in this run)") if traffic else None,
-                     "kernels": "all three kernels of a step (the scope of `value`)", "kernels_ms": kernels_ms,
+                     "kernels": "all three kernels of a step, batches overlapped as in the timed loop (the scope of `value`)",
+                     "ms_per_step_this_rank": step_ms_value, "kernels_ms_one_at_a_time": kernels_ms,
                      "algorithmic_bytes_per_read": bytes_per_read,
                      "dominant_kernel": {"kernel": demux_name, "kernel_ms_avg": k_b, "achieved": dom_achieved,
                                          "frac": dom_achieved / HBM_PEAK_GBPS},
@@ -565,6 +608,7 @@ def main():
     }
     if valu:
         out["valu_roofline"] = valu
+    cp.set_streams(1)
     if solo and not a.no_extras and a.config == "c2":
         del db
         torch.cuda.empty_cache()

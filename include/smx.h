@@ -202,6 +202,14 @@ int smx_batch_run_device(const smx_panel *panel, void *stream, const uint8_t *d_
                          uint32_t *d_n_extra, uint64_t *d_counts, smx_hit *d_hits, int8_t *d_bdist);
 
 /*
+ * Tell the panel how many batches the caller keeps in flight on as many streams (default 1).  The demux kernel is a
+ * persistent launch sized to the CUs' resident workgroup slots; with n batches in flight each launch takes 1/n of them, so
+ * that kernels of different batches run side by side (the next batch's prescan beside this batch's demux kernel) instead
+ * of queueing behind a launch that fills the machine.  Takes effect from the next launch; call it between batches.
+ */
+int smx_panel_set_streams(smx_panel *panel, int n_streams);
+
+/*
  * Diagnostic: per-kernel device times of smx_batch_run_device on this panel.  enable != 0 makes every following launch
  * record HIP events around its kernels (transpose, primer DP, demux) on the launch stream; with ms != NULL the call waits
  * for the most recent instrumented launch and writes its three durations in milliseconds (0 for a kernel that did not

@@ -58,6 +58,7 @@ SYMBOLS = [
     ("smx_batch_run_device", C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, _P, C.c_uint32, _P, _P, _P, _P]),
     ("smx_batch_run", C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, C.c_uint32, C.POINTER(C.c_uint32), _P, _P, _P]),
     ("smx_debug_kernel_times", C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    ("smx_panel_set_streams", C.c_int, [_P, C.c_int]),
     ("smx_lane_create", C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
     ("smx_lane_destroy", None, [_P]),
     ("smx_lane_windows", _P, [_P]),

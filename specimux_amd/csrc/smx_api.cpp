@@ -155,6 +155,7 @@ struct smx_panel {
     // for the nitems alignments the match words flag; a tile that needs more goes on the overflow list and is redone by a
     // dense launch (R, lds) right behind the compact one.  nitems == 0: off.
     int Rc = 0, nitems = 0, blocks_per_cu_c = 1;
+    int share = 1;      // smx_panel_set_streams: batches the caller keeps in flight on as many streams
     size_t lds_c = 0;
     DevBuf ovf[SMX_MAX_STREAMS];             // per stream slot: overflow list, one entry per compact tile
     hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};   // smx_debug_kernel_times: start, after transpose, after DP, end
@@ -666,14 +667,17 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         if (P->kev_on) (void)hipEventRecord(P->kev[2], (hipStream_t)stream);
     }
     uint32_t tiles = (n_reads + R - 1) / R;
-    int grid = (int)std::min<uint32_t>(tiles, (uint32_t)(P->n_cu * (use_slots ? P->blocks_per_cu_slots : P->blocks_per_cu)));
+    // (batches in flight on several streams share the CUs' workgroup slots: each demux launch takes its part of them, so
+    // that the next batch's memory-bound and VALU-bound prescan kernels run beside this batch's latency-bound demux kernel)
+    auto slots_of = [&](int blocks) { return (uint32_t)(P->n_cu * std::max(1, (blocks + P->share - 1) / P->share)); };
+    int grid = (int)std::min<uint32_t>(tiles, slots_of(use_slots ? P->blocks_per_cu_slots : P->blocks_per_cu));
     int e;
     if (compact) {
         // compact launch over all reads, then the dense launch over the reads of the tiles it put on the overflow list
         // (usually none: its workgroups find an empty list and leave)
         smx::DemuxAux ax = {(const unsigned *)P->pre_match[slot].p, (unsigned *)P->ovf[slot].p, P->nitems, 0, P->Rc, 1, d_codes2, d_naflag};
         const uint32_t ctiles = (n_reads + P->Rc - 1) / P->Rc;
-        const int cgrid = (int)std::min<uint32_t>(ctiles, (uint32_t)(P->n_cu * P->blocks_per_cu_c));
+        const int cgrid = (int)std::min<uint32_t>(ctiles, slots_of(P->blocks_per_cu_c));
         e = smx_launch_demux(&P->hp, P->use64, P->Rc, cgrid, P->lds_c, stream, d_windows, d_lens, n_reads, d_ops, d_extra,
                              extra_cap, d_n_extra, d_counts, d_hits, d_bdist, tc, 0, d_pre, npad, &ax);
         if (e == 0 && P->env_debug_overflow) {   // diagnostic: how many compact tiles went on the overflow list
@@ -708,6 +712,12 @@ int smx_unpack_windows_device(const smx_panel *Pc, void *stream, const uint8_t *
     if (rc) return rc;
     int e = smx_launch_unpack_windows(stream, d_packed, d_windows, n_reads, P->hp.S, (int)smx_packed_stride_for(P->hp.S), P->hp.wstride, P->n_cu);
     if (e != 0) return fail(SMX_ERR_DEVICE, "unpack kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return SMX_OK;
+}
+
+int smx_panel_set_streams(smx_panel *P, int n_streams) {
+    if (!P || n_streams < 1 || n_streams > SMX_MAX_STREAMS) return fail(SMX_ERR_ARG, "n_streams outside 1..%d", SMX_MAX_STREAMS);
+    P->share = n_streams;
     return SMX_OK;
 }
 

@@ -136,6 +136,11 @@ class CompiledPanel:
         self.bdist_per_read = lib.smx_bdist_per_read(handle)
         self.max_barcodes = self.bdist_per_read // self.hits_per_read
 
+    def set_streams(self, n: int):
+        """The caller keeps n batches in flight on n streams (smx_panel_set_streams): each demux launch then takes 1/n of
+        the CUs' workgroup slots and kernels of different batches run side by side."""
+        _lib.check(self._lib.smx_panel_set_streams(self.handle, int(n)))
+
     def close(self):
         if self.handle is not None:
             self._lib.smx_panel_destroy(self.handle)

@@ -493,7 +493,13 @@ def main():
     # memory-bound transpose and VALU-bound DP kernels run beside this batch's latency-bound demux kernel.  Measured on
     # configs[1]: two streams +7 % over one; on the 8-primer panel nothing (its DP and compact demux kernels already fill the CUs).
     n_streams = a.streams if a.streams else (2 if a.config == "c2" else 1)
-    streams = [stream] + [torch.cuda.Stream() for _ in range(n_streams - 1)]
+    if n_streams > 1:
+        # none of them the legacy default stream: a launch there waits for, and holds up, the work of every other stream
+        streams = [torch.cuda.Stream() for _ in range(n_streams)]
+        stream = streams[0]
+        torch.cuda.set_stream(stream)      # torch's own (tiny) operations on the counts go there too
+    else:
+        streams = [stream]
     db = DeviceBatches(lib, cp, sets, dev, streams)
     cp.set_streams(n_streams)
     d_counts = db.counts

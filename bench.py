@@ -298,11 +298,11 @@ class DeviceBatches:
         self.windows = [torch.from_numpy(r.windows(cp.window_stride)).to(dev) for r in read_sets]
         self.lens = [torch.from_numpy(r.lens).to(dev) for r in read_sets]
         self.extra_cap = self.n
+        # one counts vector for all streams (the kernels add to it with global atomics); records per stream
+        self.counts = torch.zeros(cp.counts_len, dtype=torch.int64, device=dev)
         self.out = [dict(ops=torch.empty(self.n * 32, dtype=torch.uint8, device=dev),
                          extra=torch.empty(self.extra_cap * 32, dtype=torch.uint8, device=dev),
-                         nextra=torch.zeros(4, dtype=torch.int32, device=dev),
-                         counts=torch.zeros(cp.counts_len, dtype=torch.int64, device=dev)) for _ in self.streams]
-        self.counts = self.out[0]["counts"]
+                         nextra=torch.zeros(4, dtype=torch.int32, device=dev)) for _ in self.streams]
         self.nextra = self.out[0]["nextra"]
         torch.cuda.synchronize()
 
@@ -313,20 +313,10 @@ class DeviceBatches:
         self._lib.check(self.lib.smx_batch_run_device(
             self.cp.handle, C.c_void_p(st.cuda_stream), C.c_void_p(self.windows[b].data_ptr()),
             C.c_void_p(self.lens[b].data_ptr()), self.n, C.c_void_p(o["ops"].data_ptr()), C.c_void_p(o["extra"].data_ptr()),
-            self.extra_cap, C.c_void_p(o["nextra"].data_ptr()), C.c_void_p(o["counts"].data_ptr()), None, None))
+            self.extra_cap, C.c_void_p(o["nextra"].data_ptr()), C.c_void_p(self.counts.data_ptr()), None, None))
 
     def zero_counts(self):
-        for o in self.out:
-            o["counts"].zero_()
-
-    def total_counts(self):
-        """Sum of the per-stream counts vectors, left in stream 0's buffer (what the all-reduce then sums over the ranks)."""
-        import torch
-        torch.cuda.synchronize()
-        for o in self.out[1:]:
-            self.out[0]["counts"] += o["counts"]
-            o["counts"].zero_()
-        return self.out[0]["counts"]
+        self.counts.zero_()
 
     def max_extra(self):
         return max(int(o["nextra"][0].item()) for o in self.out)
@@ -523,7 +513,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         db.step(i)
-    d_counts = db.total_counts()                       # (waits for every stream; adds the per-stream counts vectors)
+    if n_streams > 1:
+        torch.cuda.synchronize()                       # every stream's batches are done: the counts vector is complete
     reducer.allreduce_(d_counts, stream.cuda_stream)   # the one exchange of the path: counts, once per job
     torch.cuda.synchronize()
     barrier()

@@ -1022,3 +1022,52 @@ def test_user_prefilter_matches_oracle(lib, c2, c3, flags):
         # and it is not the Bloom / no-prefilter answer by accident
         plain, _t, _m = both.product_ops(reads)
         assert [k[:3] for k in plain] != [k[:3] for k in got]
+
+
+def test_batches_in_flight_on_two_streams(lib, c2, c3):
+    """smx_panel_set_streams(2): two batches in flight on two HIP streams, every persistent demux launch sized to half of the
+    CUs' workgroup slots, kernels of the two batches running side by side.  Records, extra records and counts of every batch
+    equal those of the same batch run alone through the host-buffer path (which the other tests pin to the oracle) -- for
+    the dense two-primer kernel and the compact + redo launches of the 8-primer panel."""
+    import torch
+    from specimux_amd import _lib, synth
+    from specimux_amd.demultiplex import compiled_panel
+    dev = torch.device("cuda", 0)
+    for name, (pan, (pf, sf)), n in (("c2", c2, 150_000), ("c3", c3, 100_000)):
+        both = Both(pf, sf)
+        cp = compiled_panel(both.specimens, both.parameters, both.args, both.prefilter)
+        sets = [synth.make_reads(pan, n, 6100 + b, workers=8, n_frac=0.01) for b in range(2)]
+        alone = []
+        for rs in sets:
+            ops, extra, counts = cp.run(rs.windows(cp.window_stride), rs.lens)
+            alone.append((ops.copy(), np.sort(extra, order=["read", "sample", "trim_start", "p1", "p2", "barcode", "rtype"]), counts.copy()))
+        cp.set_streams(2)
+        try:
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            bufs = []
+            for rs in sets:
+                bufs.append(dict(w=torch.from_numpy(rs.windows(cp.window_stride)).to(dev), l=torch.from_numpy(rs.lens).to(dev),
+                                 ops=torch.zeros(n * 32, dtype=torch.uint8, device=dev), extra=torch.zeros(n * 32, dtype=torch.uint8, device=dev),
+                                 ne=torch.zeros(4, dtype=torch.int32, device=dev), counts=torch.zeros(cp.counts_len, dtype=torch.int64, device=dev)))
+            torch.cuda.synchronize()
+            for rep in range(4):   # interleaved launches: batch 0 on stream 0, batch 1 on stream 1, four rounds
+                for k, b in enumerate(bufs):
+                    b["counts"].zero_()
+                torch.cuda.synchronize()
+                for _round in range(2):
+                    for k, b in enumerate(bufs):
+                        _lib.check(lib.smx_batch_run_device(cp.handle, C.c_void_p(streams[k].cuda_stream), C.c_void_p(b["w"].data_ptr()),
+                                                            C.c_void_p(b["l"].data_ptr()), n, C.c_void_p(b["ops"].data_ptr()),
+                                                            C.c_void_p(b["extra"].data_ptr()), n, C.c_void_p(b["ne"].data_ptr()),
+                                                            C.c_void_p(b["counts"].data_ptr()), None, None))
+                torch.cuda.synchronize()
+                for k, b in enumerate(bufs):
+                    ops = b["ops"].cpu().numpy().view(_lib.OP_DTYPE)
+                    ne = int(b["ne"][0].item())
+                    extra = np.sort(b["extra"].cpu().numpy().view(_lib.OP_DTYPE)[:ne], order=["read", "sample", "trim_start", "p1", "p2", "barcode", "rtype"])
+                    counts = b["counts"].cpu().numpy().astype(np.uint64)
+                    assert np.array_equal(ops, alone[k][0]), (name, rep, k)
+                    assert np.array_equal(extra, alone[k][1]), (name, rep, k)
+                    assert np.array_equal(counts, 2 * alone[k][2]), (name, rep, k)   # (two launches per batch and round)
+        finally:
+            cp.set_streams(1)

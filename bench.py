@@ -385,6 +385,15 @@ def side_config(lib, config, dev, stream, tmp, n_reads=1_000_000, steps=10):
            "step_kernels": step_kernel_list(k_t, k_d, k_b, "smx::demux_kernel<unsigned int, 256, 1, 1, ...> (compact + redo launch)"),
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                         "algorithmic_bytes_per_read": bpr, "kernels_ms": kernels_ms}}
+    prof = committed_profile(f"r03_{config}_pmc_summary.json")
+    if prof and prof.get("reads_per_launch") == n_reads:
+        out["roofline"]["traffic"] = prof.get("hbm_bytes_per_step")
+        out["roofline"]["traffic_source"] = (f"profiles/r03_{config}_pmc_summary.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE over the "
+                                             "kernels of a step; replayed, not measured in this run)")
+        if prof.get("valu_instr_per_step"):
+            out["valu_roofline"] = {"instr_per_step": prof["valu_instr_per_step"],
+                                    "frac": prof["valu_instr_per_step"] / (kernels_ms * 1e-3) / VALU_PEAK_GUIDE,
+                                    "source": "instruction counts replayed from the same committed profile"}
     del db
     torch.cuda.empty_cache()
     return out

@@ -435,7 +435,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)   # skip other_configs / pcie_inclusive / end_to_end (profiling runs)
     ap.add_argument("--e2e-reads", type=int, default=N_READS, help=argparse.SUPPRESS)
     ap.add_argument("--rotate", type=int, default=N_ROTATE, help=argparse.SUPPRESS)   # resident input batches (1: relaunch in place)
-    ap.add_argument("--streams", type=int, default=None, help=argparse.SUPPRESS)      # batches in flight (default: 2 on configs[1], else 1)
+    ap.add_argument("--streams", type=int, default=None, help=argparse.SUPPRESS)      # batches in flight (default: 3 on configs[1], else 1)
     ap.add_argument("--trim", default=None, help=argparse.SUPPRESS)   # e.g. tails: not the headline flags, DESIGN.md side numbers
     ap.add_argument("--cli-args", default="", help=argparse.SUPPRESS)  # extra specimux flags for side measurements, e.g. "-e 4"
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"], help=argparse.SUPPRESS)   # c3: 3072 specimens / 4 pools; c5: + 160-nt windows, 15 % errors
@@ -490,8 +490,9 @@ def main():
     # Batches in flight: the timed loop hands the steps round robin to n_streams HIP streams (smx_batch_run_device takes the
     # stream; smx_panel_set_streams sizes each persistent demux launch to its share of the CUs), so that the next batch's
     # memory-bound transpose and VALU-bound DP kernels run beside this batch's latency-bound demux kernel.  Measured on
-    # configs[1]: two streams +7 % over one; on the 8-primer panel nothing (its DP and compact demux kernels already fill the CUs).
-    n_streams = a.streams if a.streams else (2 if a.config == "c2" else 1)
+    # configs[1], two passes each: one stream 0.326-0.333 ms per step, two 0.315, three 0.307-0.309, four 0.44 (a quarter of
+    # the slots per launch is too few); on the 8-primer panel nothing (its DP and compact demux kernels already fill the CUs).
+    n_streams = a.streams if a.streams else (3 if a.config == "c2" else 1)
     if n_streams > 1:
         # none of them the legacy default stream: a launch there waits for, and holds up, the work of every other stream
         streams = [torch.cuda.Stream() for _ in range(n_streams)]

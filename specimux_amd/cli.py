@@ -97,6 +97,10 @@ def main(argv=None):
     logging.info(f"Starting {version()}")
     logging.info(f"Command line: {' '.join(argv)}")
     from . import orchestration
+    if args.output_to_files and args.threads > 0 and "SMX_IO_THREADS" not in os.environ:
+        # -t N (the reference's worker-pool size, orchestration.py:175): here the size of the host I/O pool -- reader, window
+        # packer and writer threads -- read by libsmx.so when it is first used; the matching itself needs no host threads
+        os.environ["SMX_IO_THREADS"] = str(args.threads)
     if args.output_to_files:
         orchestration.specimux_mp(args)
     else:

@@ -618,12 +618,19 @@ PRIMER_SHAPES = {
     "28nt_degenerate_primer": "CTTGGTCATYTAGAGGARGTAAAAGTCG",    # -> <31, 4>
     "20nt_degenerate_primer": "GAYGAYMGWGATCAYTTYGG",            # -> <22, 4>
 }
+# the same with the degenerate primer SECOND in the panel (primer index 1): the DP kernel reads its letter sets from the
+# kernel-argument struct at a primer-dependent offset, and a scalar load with a misaligned base register silently fetches
+# another primer's (seen in a variant of the kernel for every primer index that is not a multiple of 4)
+REVERSE_PRIMER_SHAPES = {
+    "20nt_degenerate_reverse_primer": "TCCTCCGCTTATTGATRTGY",          # -> <22, 4>, degenerate letters at primer 1
+    "26nt_degenerate_reverse_primer": "TCCTCCGCTTATTGATATGCRYAAGT",    # -> <31, 4>, degenerate letters at primer 1
+}
 
 
 @pytest.mark.parametrize("shape", ["96x4_multiword", "24nt_barcodes", "40nt_primer_64bit", "mixed_lengths",
                                    "8nt_barcodes", "10nt_barcodes", "16nt_barcodes", "16nt_barcodes_k4",
                                    "16nt_barcodes_k6", "8nt_barcodes_k4", "96x4_multiword_k5", "40nt_primer_64bit_k5"]
-                         + sorted(PRIMER_SHAPES))
+                         + sorted(PRIMER_SHAPES) + sorted(REVERSE_PRIMER_SHAPES))
 def test_panel_shapes(lib, tmp_path_factory, monkeypatch, shape):
     from specimux_amd import synth
     flags = {}
@@ -641,6 +648,8 @@ def test_panel_shapes(lib, tmp_path_factory, monkeypatch, shape):
                                       fwd_primer="CTTGGTCATTTAGAGGAAGTAAAAGTCGTAACAAGGTTTCC")
     elif shape in PRIMER_SHAPES:
         pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 8, 6, 13, 6, fwd_primer=PRIMER_SHAPES[shape])
+    elif shape in REVERSE_PRIMER_SHAPES:
+        pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 8, 6, 13, 6, rev_primer=REVERSE_PRIMER_SHAPES[shape])
     elif shape.endswith("nt_barcodes"):   # the padded bit-sliced scan's other heights: M = 8, 12, 16 rows
         n = int(shape.split("nt")[0])
         pan, (pf, sf) = _custom_panel(tmp_path_factory, shape, 8, 6, n, {8: 4, 10: 5, 16: 7}[n])
@@ -654,7 +663,7 @@ def test_panel_shapes(lib, tmp_path_factory, monkeypatch, shape):
         both.assert_hits_equal(reads[:80], f"{name} {fl}")
         got = both.assert_ops_equal(reads, f"{name} {fl}")
         assert sum(1 for k in got if k[6] == "DEREP") > 100
-    if name in PRIMER_SHAPES:
+    if name in PRIMER_SHAPES or name in REVERSE_PRIMER_SHAPES:
         # the same DP kernel with the match words compiled in (<rows, symbols, 1>: what panels with compact demux tiles run),
         # compact tiles forced on, with a capacity that sends part of the tiles through the overflow list; short reads too
         monkeypatch.setenv("SMX_COMPACT_ITEMS", "120")

@@ -25,7 +25,7 @@ import numpy as np
 from . import _lib
 from .native_io import Lane, Reader, Writer
 
-BATCH_READS = 131072          # reads per kernel launch
+BATCH_READS = int(os.environ.get("SMX_BATCH_READS", "131072"))   # reads per kernel launch (tuning hook: tools/e2e_sweep.py)
 BATCH_BYTES = 256 << 20       # ... or this many bytes of input, whichever comes first
 N_LANES = 3
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SMX_ABI_VERSION 3
+#define SMX_ABI_VERSION 4
 
 typedef enum {
     SMX_OK = 0,
@@ -333,6 +333,12 @@ int smx_writer_open(const char *output_dir, const char *prefix, int is_fastq, co
 int smx_writer_write(smx_writer *writer, const smx_batch *batch, const smx_op *ops, uint32_t n_reads,
                      const smx_op *extra, uint32_t n_extra);
 int smx_writer_close(smx_writer *writer);   /* flushes; returns the first I/O error seen, if any */
+
+/* ---- run setup helper (host only)
+ * Minimum global edit distance (exact character equality) over all pairs of the n strings seqs[off[i]..off[i+1]):
+ * what setup_match_parameters derives the default barcode threshold from (reference orchestration.py:548-575,
+ * edlib.align(a, b, task="distance") over itertools.combinations).  *out_min = -1 for n < 2. */
+int smx_min_pairwise_distance(const char *seqs, const uint32_t *off, uint32_t n, int32_t *out_min);
 
 #ifdef __cplusplus
 }

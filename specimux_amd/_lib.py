@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMX_LIB") or os.path.join(_HERE, "libsmx.so")   # SMX_LIB: A/B builds (tools/tune.sh)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_DEVICE, ERR_OVERFLOW = 0, -1, -2, -3, -4
 TRIM = {"none": 0, "tails": 1, "barcodes": 2, "primers": 3}
 DEREP = {"none": 0, "best": 1}
@@ -68,6 +68,7 @@ SYMBOLS = [
     ("smx_packed_stride", C.c_size_t, [_P]),
     ("smx_pack_windows4", C.c_int, [_P, _P, C.c_uint32, C.c_int32, _P, _P, C.POINTER(C.c_uint32)]),
     ("smx_pack_windows4_batch", C.c_int, [_P, C.c_int32, _P, _P, C.POINTER(C.c_uint32)]),
+    ("smx_min_pairwise_distance", C.c_int, [C.c_char_p, _P, C.c_uint32, C.POINTER(C.c_int32)]),
     ("smx_unpack_windows_device", C.c_int, [_P, _P, _P, C.c_uint32, _P]),
     ("smx_lane_wait", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_uint32), _P]),
     ("smx_align", C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),

@@ -326,10 +326,10 @@ def cleanup_empty_directories(output_dir: str):
         if dirpath == output_dir:
             continue
         try:
+            if any(f not in meta for f in filenames):   # the cheap test first: a directory of 768 sample files is not stat'ed
+                continue
             entries = os.listdir(dirpath)
             if any(os.path.isdir(os.path.join(dirpath, e)) for e in entries):
-                continue
-            if any(f not in meta for f in filenames):
                 continue
             for f in filenames:
                 os.remove(os.path.join(dirpath, f))

@@ -48,6 +48,22 @@ def edit_distance(a: str, b: str) -> int:
     return score
 
 
+def _native_min_pairwise(seqs) -> int:
+    """min over all pairs of edit_distance(x, y), in libsmx (smx_min_pairwise_distance): a 224-barcode panel has 25,000
+    pairs, which the Python loop above takes a second over."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    enc = [s.encode("utf-8") for s in seqs]
+    if any(len(e) != len(s) for e, s in zip(enc, seqs)):   # non-ASCII text: compare code points, not bytes
+        return min(edit_distance(x, y) for x, y in itertools.combinations(seqs, 2))
+    off = np.zeros(len(enc) + 1, dtype=np.uint32)
+    off[1:] = np.cumsum([len(e) for e in enc])
+    out = C.c_int32()
+    _lib.check(_lib.load().smx_min_pairwise_distance(b"".join(enc), _lib.ptr(off), len(enc), C.byref(out)))
+    return int(out.value)
+
+
 def _bp_adjusted_length(primer: str) -> float:
     weight = {**dict.fromkeys("ACGT", 3), **dict.fromkeys("KMRSWY", 2), **dict.fromkeys("BDHV", 1)}
     return sum(weight.get(ch, 0) for ch in primer) / 3.0
@@ -56,7 +72,7 @@ def _bp_adjusted_length(primer: str) -> float:
 def _min_pairwise(seqs, label, args):
     if len(seqs) <= 1:
         return None
-    best = min(edit_distance(x, y) for x, y in itertools.combinations(seqs, 2))
+    best = _native_min_pairwise(seqs)
     if getattr(args, "diagnostics", None):
         logging.info(f"Minimum edit distance is {best} for {label}")
     return best

@@ -27,6 +27,7 @@ from .native_io import Lane, Reader, Writer
 
 BATCH_READS = int(os.environ.get("SMX_BATCH_READS", "131072"))   # reads per kernel launch (tuning hook: tools/e2e_sweep.py)
 BATCH_BYTES = 256 << 20       # ... or this many bytes of input, whichever comes first
+FIRST_BATCH_READS = 32768     # the first batch is small: the writer (the longest stage) starts that much earlier
 N_LANES = 3
 
 
@@ -38,10 +39,8 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
     keep_batch = [0]   # stride = (rank, world): batch i belongs to rank i % world (inputs that cannot be cut by byte range)
     writer = Writer(output_dir, prefix, reader.is_fastq, panel)
     counts = np.zeros(panel.counts_len, dtype=np.uint64)
-    lanes = [Lane(panel, BATCH_READS) for _ in range(N_LANES)]
+    lanes = []
     free_lanes, q_gpu, q_out = queue.Queue(), queue.Queue(maxsize=N_LANES), queue.Queue(maxsize=N_LANES)
-    for ln in lanes:
-        free_lanes.put(ln)
     errors = []
     ascii_lanes = bool(os.environ.get("SMX_LANES_ASCII"))   # A/B and test hook: ship 8-bit windows
     timing = {"read": 0.0, "pack": 0.0, "submit": 0.0, "gpu_wait": 0.0, "write": 0.0, "close": 0.0}
@@ -58,8 +57,11 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                     break
                 to_skip -= len(b)
                 b.close()
+            first = True
             while (left is None or left > 0) and not errors:
-                want = BATCH_READS if left is None else min(BATCH_READS, left)
+                want = min(BATCH_READS, FIRST_BATCH_READS) if first else BATCH_READS
+                want = want if left is None else min(want, left)
+                first = False
                 t0 = time.perf_counter()
                 b = reader.next_batch(want, BATCH_BYTES)
                 if b is None:
@@ -121,6 +123,10 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
     tp.start()
     tc.start()
     try:
+        # the lanes (pinned staging, device buffers, a stream each) are created while the reader parses its first batch
+        for _ in range(N_LANES):
+            lanes.append(Lane(panel, BATCH_READS))
+            free_lanes.put(lanes[-1])
         while True:
             item = q_gpu.get()
             if item is None:
@@ -157,8 +163,11 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                 pass
             free_lanes.put(None)
             tp.join(timeout=0.05)
-        reader.close()
+        # unmapping a large input takes tens of milliseconds: it runs beside the writer's last flushes and the lanes' teardown
+        t_unmap = threading.Thread(target=reader.close, name="smx-unmap", daemon=True)
+        t_unmap.start()
     if errors:
+        t_unmap.join()
         try:
             writer.close()
         except Exception:
@@ -174,6 +183,7 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
     timing["close"] = time.perf_counter() - t0
     for ln in lanes:
         ln.close()
+    t_unmap.join()
     timing["wall"] = time.perf_counter() - t_start
     if int(counts[_lib.CNT_TOTAL]) != n_delivered[0]:
         raise RuntimeError(f"pipeline accounting: the reader delivered {n_delivered[0]} reads, the kernels counted "

@@ -341,3 +341,39 @@ def test_threaded_writer_equals_oracle_tree(tmp_path):
     for path, recs in tree.items():
         text = open(os.path.join(tmp_path, "out", path)).read()
         assert text == "".join(recs), path
+
+
+def test_writer_reverse_complement_every_length_and_letter(tmp_path):
+    """The writer reverse-complements 16 bytes per step (smx_io.cpp revcomp_copy / reverse_copy): every record length
+    0..70 with every trim offset 0..3, over IUPAC letters in both cases, 'U', and bytes outside the alphabet, against
+    str.translate of the reference's table (models.py: Bio.Seq.reverse_complement semantics) and a reversed quality."""
+    from specimux_amd import _lib
+    from specimux_amd.models import reverse_complement
+    from specimux_amd.native_io import Reader, Writer
+
+    class FakePanel:
+        specimen_ids, pools, primer_names, barcodes = ["s"], ["P"], ["F", "R"], ["ACGT"]
+    rng = np.random.default_rng(5)
+    letters = "ACGTMRWSYKVHDBXNUacgtmrwsykvhdbxnu*-.?"
+    recs = []
+    for L in range(1, 71):
+        for k in range(4):
+            seq = "".join(letters[j] for j in rng.integers(0, len(letters), L))
+            qual = "".join(chr(33 + int(j)) for j in rng.integers(0, 60, L))
+            recs.append((f"r{L}_{k}", seq, qual, k if k < L else 0))
+    fq = tmp_path / "in.fastq"
+    fq.write_text("".join(f"@{i}\n{s}\n+\n{q}\n" for i, s, q, _ in recs))
+    batch = Reader(os.fspath(fq)).next_batch(len(recs) + 1)
+    assert len(batch) == len(recs)
+    ops = np.zeros(len(recs), dtype=_lib.OP_DTYPE)
+    for i, (_id, s, _q, k) in enumerate(recs):
+        ops[i] = (0, k, max(k, len(s) - (k + 1) // 2), 0, 0, 1, -1, [0, 0, 0, 0], _lib.R_DEREP_FULL, _lib.OPF_REVERSE, 1, i)
+    w = Writer(os.fspath(tmp_path / "o"), "", True, FakePanel)
+    w.write(batch, ops, np.zeros(0, dtype=_lib.OP_DTYPE))
+    w.close()
+    exp = ""
+    for (rid, s, q, k), op in zip(recs, ops):
+        a, e = int(op["trim_start"]), int(op["trim_end"])
+        exp += f"@{rid} 0,0,0,0 pool=P primers=F+R s\n{reverse_complement(s)[a:e]}\n+\n{q[::-1][a:e]}\n"
+    assert (tmp_path / "o/full/P/F-R/s.fastq").read_text() == exp
+    assert (tmp_path / "o/full/P/s.fastq").read_text() == exp

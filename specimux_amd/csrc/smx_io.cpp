@@ -107,8 +107,19 @@ struct smx_batch {
     std::vector<uint32_t> first;          // first[i] = global index of segs[i].recs[0]; first.back() = total
     std::shared_ptr<void> block;   // fast engine: what the segments point into (a file mapping, or an inflated / copied block)
     uint32_t n = 0;
+    // mapped input: the whole pages only this batch's records lie in.  Dropping their page-table entries when the batch
+    // goes (madvise, the mapping itself stays reserved) spreads the cost of unmapping a large file -- ~20 ms per GB,
+    // otherwise paid in one piece after the last record is written -- over the run, on whichever thread retires batches.
+    char *rel_lo = nullptr;
+    size_t rel_n = 0;
 
-    void clear() { segs.clear(); first.clear(); block.reset(); n = 0; }
+    void release_pages() {
+        if (rel_n) madvise(rel_lo, rel_n, MADV_DONTNEED);
+        rel_lo = nullptr;
+        rel_n = 0;
+    }
+    void clear() { segs.clear(); first.clear(); release_pages(); block.reset(); n = 0; }
+    ~smx_batch() { release_pages(); }
     void finish() {
         first.assign(segs.size() + 1, 0);
         for (size_t i = 0; i < segs.size(); i++) first[i + 1] = first[i] + (uint32_t)segs[i].recs.size();
@@ -426,6 +437,12 @@ int next_fast(smx_reader *r, uint32_t max_reads, uint64_t max_bytes, smx_batch *
             if (rc == 0) return 0;
             if (rc == 3) { r->fpos = r->fsize; return 1; }
             if (rc == 2) { want *= 2; continue; }
+            if (b->block) {   // records placed: [fpos, fpos + next_off) belongs to this batch alone, minus its two edge pages
+                const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+                const uintptr_t lo = ((uintptr_t)(r->map->p + r->fpos) + page - 1) & ~(page - 1);
+                const uintptr_t hi = (uintptr_t)(r->map->p + r->fpos + next_off) & ~(page - 1);
+                if (hi > lo) { b->rel_lo = (char *)lo; b->rel_n = (size_t)(hi - lo); }
+            }
             r->fpos += next_off;
             return 1;
         }

@@ -109,8 +109,8 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                 t0 = time.perf_counter()
                 if not errors:
                     writer.write(b, ops, extra)
-                b.close()
                 free_lanes.put(lane)
+                q_retire.put(b)
                 timing["write"] += time.perf_counter() - t0
         except BaseException as e:
             errors.append(e)
@@ -118,10 +118,24 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
             while q_out.get() is not None:   # keep draining so the main thread never blocks
                 pass
 
+    q_retire = queue.SimpleQueue()
+
+    def retire():
+        # freeing a batch drops the page-table entries of its part of the mapped input (smx_io.cpp smx_batch): off the
+        # writer's thread, which is the longest stage; the reader's mapping goes last
+        while True:
+            b = q_retire.get()
+            if b is None:
+                break
+            b.close()
+        reader.close()
+
     tp = threading.Thread(target=produce, name="smx-reader", daemon=True)
     tc = threading.Thread(target=consume, name="smx-writer", daemon=True)
+    tr = threading.Thread(target=retire, name="smx-retire", daemon=True)
     tp.start()
     tc.start()
+    tr.start()
     try:
         # the lanes (pinned staging, device buffers, a stream each) are created while the reader parses its first batch
         for _ in range(N_LANES):
@@ -163,11 +177,9 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
                 pass
             free_lanes.put(None)
             tp.join(timeout=0.05)
-        # unmapping a large input takes tens of milliseconds: it runs beside the writer's last flushes and the lanes' teardown
-        t_unmap = threading.Thread(target=reader.close, name="smx-unmap", daemon=True)
-        t_unmap.start()
+        q_retire.put(None)
     if errors:
-        t_unmap.join()
+        tr.join()
         try:
             writer.close()
         except Exception:
@@ -183,7 +195,7 @@ def run_streaming(sequence_file, panel, output_dir, prefix, start_seq=1, num_seq
     timing["close"] = time.perf_counter() - t0
     for ln in lanes:
         ln.close()
-    t_unmap.join()
+    tr.join()
     timing["wall"] = time.perf_counter() - t_start
     if int(counts[_lib.CNT_TOTAL]) != n_delivered[0]:
         raise RuntimeError(f"pipeline accounting: the reader delivered {n_delivered[0]} reads, the kernels counted "

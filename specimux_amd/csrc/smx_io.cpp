@@ -19,8 +19,12 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -28,6 +32,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -42,6 +47,23 @@ extern "C" int smx_set_error(int code, const char *fmt, ...);   // smx_api.cpp (
 namespace {
 
 inline bool is_space(unsigned char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
+
+// any white space in [p, e)?  Every base of the input passes through here (a wrapped or blank-padded sequence line sends
+// the file to the general engine): 16 bytes per step -- no byte of a clean line is <= ' ' -- and the byte loop only for a
+// block that holds one (a control character is not white space).
+inline bool has_space(const char *p, const char *e) {
+#if defined(__SSE2__)
+    const __m128i sp = _mm_set1_epi8(0x20);
+    for (; p + 16 <= e; p += 16) {
+        const __m128i v = _mm_loadu_si128((const __m128i *)p);
+        if (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(v, sp), v))) {
+            for (int k = 0; k < 16; k++) if (is_space((unsigned char)p[k])) return true;
+        }
+    }
+#endif
+    for (; p < e; p++) if (is_space((unsigned char)*p)) return true;
+    return false;
+}
 
 int io_threads() {
     static int n = [] {
@@ -338,7 +360,7 @@ bool parse_strict(const char *base, const char *p, const char *stop, const char 
         const char *qe = e4;
         while (qe > q && is_space((unsigned char)qe[-1])) qe--;
         if (se == s || (size_t)(se - s) != (size_t)(qe - q)) return false;   // empty or wrapped: general engine decides
-        for (const char *c = s; c < se; c++) if (is_space((unsigned char)*c)) return false;
+        if (has_space(s, se)) return false;
         if ((uint64_t)(se - s) > 0x7FFFFFFFull) return false;
         r.seq_off = (uint64_t)(s - base);
         r.seq_len = (uint32_t)(se - s);
@@ -543,7 +565,6 @@ std::string safe_name(const std::string &s) {   // io_utils.py:207: chars outsid
 // f(end[-1 - i]).  A byte loop runs at ~1 GB/s per core, a third of memcpy; 16 bytes per step with pshufb (the byte reversal,
 // and the complement as four 16-entry tables selected by the high nibble: every letter lives in 0x40..0x7F) runs at memcpy speed.
 #if defined(__x86_64__)
-#include <immintrin.h>
 namespace {
 __attribute__((target("ssse3"))) void reverse_copy_ssse3(char *o, const char *end, size_t n) {
     const __m128i rev = _mm_set_epi8(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
@@ -599,13 +620,46 @@ struct smx_writer {
     bool fastq = true;
     std::vector<std::string> specimens, pools, primers, barcodes;
     unsigned char comp[256];
-    struct File { std::string path; std::string pending; bool dir_made = false; };
+    // What a file still has to receive: pieces that are either literal bytes (an offset into `lit`: record headers,
+    // separators, reverse-complemented bodies) or pointers into the batch's input (forward reads are written straight
+    // from the parsed input -- the mapped page cache -- by writev: no formatted copy of their bases and qualities exists).
+    // Input pointers die with the batch: smx_writer_write flushes every file it touched before it returns.
+    struct Piece { const char *src; size_t off, n; };   // src == nullptr: lit[off, off + n)
+    struct File {
+        std::string path, lit;
+        std::vector<Piece> pieces;
+        size_t bytes = 0;
+        bool dir_made = false, dirty = false;
+        void literal(const char *p, size_t n) {
+            if (!n) return;
+            const size_t at = lit.size();
+            lit.append(p, n);
+            if (!pieces.empty() && !pieces.back().src && pieces.back().off + pieces.back().n == at) pieces.back().n += n;
+            else pieces.push_back(Piece{nullptr, at, n});
+            bytes += n;
+        }
+        char *literal_space(size_t n) {   // n bytes of literal the caller fills in
+            const size_t at = lit.size();
+            lit.resize(at + n);
+            if (!pieces.empty() && !pieces.back().src && pieces.back().off + pieces.back().n == at) pieces.back().n += n;
+            else pieces.push_back(Piece{nullptr, at, n});
+            bytes += n;
+            return &lit[at];
+        }
+        void source(const char *p, size_t n) {
+            if (!n) return;
+            if (!pieces.empty() && pieces.back().src && pieces.back().src + pieces.back().n == p) pieces.back().n += n;
+            else pieces.push_back(Piece{p, 0, n});
+            bytes += n;
+        }
+    };
     struct Shard {   // one per writer thread: owns a disjoint set of output files
         std::vector<File> files;
+        std::vector<size_t> touched;                        // files with pending pieces (flushed at the end of the batch)
         std::unordered_map<std::string, size_t> index;
         std::unordered_map<uint64_t, size_t> by_key;        // packed (class, pool, primers, sample) -> file: no string
         std::unordered_map<uint64_t, std::string> tails;    // work per record once a file has been seen
-        std::string scratch;
+        std::vector<struct iovec> iov;
         int first_errno = 0;
         int rc = 0;
     };
@@ -619,24 +673,39 @@ struct smx_writer {
             if (path[i] == '/') { std::string d = path.substr(0, i); mkdir(d.c_str(), 0777); }
     }
     static void flush(Shard &sh, File &f) {
-        if (f.pending.empty()) return;
+        f.dirty = false;
+        if (f.pieces.empty()) return;
         if (!f.dir_made) { mkdirs(f.path); f.dir_made = true; }
         int fd = open(f.path.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0666);
-        if (fd < 0) { if (!sh.first_errno) sh.first_errno = errno; f.pending.clear(); return; }
-        const char *p = f.pending.data();
-        size_t left = f.pending.size();
-        while (left) {
-            ssize_t w = write(fd, p, left);
-            if (w < 0) { if (errno == EINTR) continue; if (!sh.first_errno) sh.first_errno = errno; break; }
-            p += w; left -= (size_t)w;
+        if (fd < 0) { if (!sh.first_errno) sh.first_errno = errno; }
+        else {
+            sh.iov.clear();
+            for (const Piece &pc : f.pieces) {
+                struct iovec v;
+                v.iov_base = (void *)(pc.src ? pc.src : f.lit.data() + pc.off);
+                v.iov_len = pc.n;
+                sh.iov.push_back(v);
+            }
+            size_t k = 0;
+            while (k < sh.iov.size()) {
+                const size_t cnt = std::min<size_t>(sh.iov.size() - k, 1024);   // IOV_MAX
+                ssize_t w = writev(fd, &sh.iov[k], (int)cnt);
+                if (w < 0) { if (errno == EINTR) continue; if (!sh.first_errno) sh.first_errno = errno; break; }
+                size_t left = (size_t)w;
+                while (k < sh.iov.size() && left >= sh.iov[k].iov_len) { left -= sh.iov[k].iov_len; k++; }
+                if (left) { sh.iov[k].iov_base = (char *)sh.iov[k].iov_base + left; sh.iov[k].iov_len -= left; }
+            }
+            close(fd);
         }
-        close(fd);
-        f.pending.clear();
+        f.pieces.clear();
+        f.lit.clear();
+        f.bytes = 0;
     }
     size_t file_for(Shard &sh, const std::string &rel) {
         auto it = sh.index.find(rel);
         if (it != sh.index.end()) return it->second;
-        sh.files.push_back(File{out_dir + "/" + rel, std::string(), false});
+        sh.files.emplace_back();
+        sh.files.back().path = out_dir + "/" + rel;
         sh.index.emplace(rel, sh.files.size() - 1);
         return sh.files.size() - 1;
     }
@@ -717,45 +786,69 @@ int write_one(smx_writer *w, smx_writer::Shard &sh, uint32_t me, uint32_t T, con
     if (e > L) e = L;
     if (e < s) e = s;
     const size_t n = (size_t)(e - s);
-    // the record is formatted straight into the first destination's pending buffer
-    std::string &dst = sh.files[mine1 ? f1 : f2].pending;
-    const size_t rec0 = dst.size();
-    dst.reserve(rec0 + r.id_len + tail.size() + 2 * n + 32);
-    dst.push_back(w->fastq ? '@' : '>');
-    dst.append(base + r.id_off, r.id_len);
-    dst.push_back(' ');
+    // header: '@' id ' ' distance code, then the per-file tail (" pool=... primers=... sample\n")
+    char head[512];
+    size_t hn = 0;
+    head[hn++] = w->fastq ? '@' : '>';
+    std::string long_head;
+    const bool big_id = (size_t)r.id_len + 64 > sizeof(head);
+    if (!big_id) { memcpy(head + hn, base + r.id_off, r.id_len); hn += r.id_len; }
+    char dist[24];
+    size_t dn = 0;
+    dist[dn++] = ' ';
     for (int k = 0; k < 4; k++) {
-        if (k) dst.push_back(',');
+        if (k) dist[dn++] = ',';
         int d = op.dist[k];
-        if (d < 0) dst.push_back('X');
-        else { if (d >= 100) dst.push_back((char)('0' + d / 100)); if (d >= 10) dst.push_back((char)('0' + (d / 10) % 10)); dst.push_back((char)('0' + d % 10)); }
+        if (d < 0) dist[dn++] = 'X';
+        else { if (d >= 100) dist[dn++] = (char)('0' + d / 100); if (d >= 10) dist[dn++] = (char)('0' + (d / 10) % 10); dist[dn++] = (char)('0' + d % 10); }
     }
-    dst += tail;
     const char *seq = base + r.seq_off;
+    const char *qual = r.qual_off == UINT64_MAX ? nullptr : base + r.qual_off;
     const bool rev = (op.flags & SMX_OPF_REVERSE) != 0;
-    size_t at = dst.size();
-    dst.resize(at + n);
-    if (!rev) memcpy(&dst[at], seq + s, n);
-    else revcomp_copy(&dst[at], seq + (L - s), n, w->comp);
-    dst.push_back('\n');
-    if (w->fastq) {
-        dst += "+\n";
-        at = dst.size();
-        dst.resize(at + n);
-        if (r.qual_off == UINT64_MAX) memset(&dst[at], 'I', n);
-        else {
-            const char *q = base + r.qual_off;
-            if (!rev) memcpy(&dst[at], q + s, n);
-            else reverse_copy(&dst[at], q + (L - s), n);
+    for (int dest = 0; dest < 2; dest++) {
+        if (dest == 0 ? !mine1 : !mine2) continue;
+        smx_writer::File &f = sh.files[dest == 0 ? f1 : f2];
+        if (!f.dirty) { f.dirty = true; sh.touched.push_back(dest == 0 ? f1 : f2); }
+        if (big_id) { f.literal(head, 1); f.literal(base + r.id_off, r.id_len); }
+        else f.literal(head, hn);
+        f.literal(dist, dn);
+        f.literal(tail.data(), tail.size());
+        if (!rev) {
+            // forward: bases and qualities go out from where the parser found them; an untrimmed record whose input
+            // lines are "SEQ\n+\nQUAL" in one piece is a single pointer
+            if (w->fastq && qual && n == (size_t)L && qual == seq + L + 3 && seq[L] == '\n' && seq[L + 1] == '+' && seq[L + 2] == '\n')
+                f.source(seq, 2 * n + 3);
+            else {
+                f.source(seq + s, n);
+                if (w->fastq) {
+                    f.literal("\n+\n", 3);
+                    if (qual) f.source(qual + s, n);
+                    else memset(f.literal_space(n), 'I', n);
+                }
+            }
+            f.literal("\n", 1);
+        } else {
+            // reverse complement: formatted once (first destination) and copied to the second
+            const size_t body = w->fastq ? 2 * n + 4 : n + 1;
+            char *o = f.literal_space(body);
+            if (dest == 1 && mine1) {
+                const smx_writer::File &f0 = sh.files[f1];
+                memcpy(o, f0.lit.data() + f0.lit.size() - body, body);
+            } else {
+                revcomp_copy(o, seq + (L - s), n, w->comp);
+                o[n] = '\n';
+                if (w->fastq) {
+                    o[n + 1] = '+';
+                    o[n + 2] = '\n';
+                    if (qual) reverse_copy(o + n + 3, qual + (L - s), n);
+                    else memset(o + n + 3, 'I', n);
+                    o[2 * n + 3] = '\n';
+                }
+            }
         }
-        dst.push_back('\n');
     }
-    if (mine1 && mine2) {   // same thread owns both files: copy the finished record
-        std::string &d2 = sh.files[f2].pending;
-        d2.append(dst, rec0, std::string::npos);
-    }
-    if (mine1 && sh.files[f1].pending.size() > w->flush_bytes) smx_writer::flush(sh, sh.files[f1]);
-    if (mine2 && sh.files[f2].pending.size() > w->flush_bytes) smx_writer::flush(sh, sh.files[f2]);
+    if (mine1 && sh.files[f1].bytes > w->flush_bytes) smx_writer::flush(sh, sh.files[f1]);
+    if (mine2 && sh.files[f2].bytes > w->flush_bytes) smx_writer::flush(sh, sh.files[f2]);
     return SMX_OK;
 }
 
@@ -1075,7 +1168,11 @@ int smx_writer_open(const char *output_dir, const char *prefix, int is_fastq, co
     for (int c = 0; c < 256; c++) w->comp[c] = (unsigned char)c;
     const char *from = "ACGTMRWSYKVHDBXNUacgtmrwsykvhdbxnu", *to = "TGCAKYWSRMBDHVXNAtgcakywsrmbdhvxna";
     for (int i = 0; from[i]; i++) w->comp[(unsigned char)from[i]] = (unsigned char)to[i];
-    w->shards.resize((size_t)io_threads());
+    {   // several shards per thread (smx_writer_write hands them out heaviest first); SMX_IO_SHARDS overrides
+        size_t ns = io_threads() > 1 ? (size_t)io_threads() * 8 : 1;
+        if (const char *e = getenv("SMX_IO_SHARDS")) ns = (size_t)std::max(1, atoi(e));
+        w->shards.resize(ns);
+    }
     if (const char *e = getenv("SMX_IO_FLUSH_KB")) w->flush_bytes = (size_t)std::max(4, atoi(e)) << 10;
     mkdir(output_dir, 0777);
     *out = w;
@@ -1101,11 +1198,12 @@ int smx_writer_write(smx_writer *w, const smx_batch *b, const smx_op *ops, uint3
     // `extra`).  Pass 2, one shard per thread: the shard walks its entries slice by slice, i.e. in read order, and
     // formats / appends them -- per-file record order is the input order, no locks, and no thread looks at an
     // operation that is not its own.
-    const uint32_t T = (uint32_t)w->shards.size();
+    const uint32_t T = (uint32_t)w->shards.size();           // shards: disjoint sets of output files
+    const uint32_t NT = (uint32_t)std::max(1, io_threads());   // threads
     std::vector<std::string> errs(T);
-    const bool threaded = T > 1 && n_reads >= 512;
-    const uint32_t P = threaded ? T : 1;
-    w->route.resize((size_t)T * T);
+    const bool threaded = NT > 1 && n_reads >= 512;
+    const uint32_t P = threaded ? NT : 1;
+    w->route.resize((size_t)P * T);
     auto route = [&](uint32_t slice) {
         std::vector<uint32_t> *mine = &w->route[(size_t)slice * T];
         for (uint32_t t = 0; t < T; t++) mine[t].clear();
@@ -1136,15 +1234,49 @@ int smx_writer_write(smx_writer *w, const smx_batch *b, const smx_op *ops, uint3
                 if (sh.rc) break;
             }
         if (sh.rc) errs[me] = smx_last_error();
+        // pieces point into the batch: nothing of it may stay pending
+        for (size_t fi : sh.touched) smx_writer::flush(sh, sh.files[fi]);
+        sh.touched.clear();
     };
     if (!threaded) { route(0); for (uint32_t t = 0; t < T; t++) work(t); }
     else {
+        static const bool dbg = getenv("SMX_IO_DEBUG") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        std::vector<double> took(NT, 0.0);
+        const double t0 = now();
         std::vector<std::thread> th;
-        for (uint32_t t = 0; t < T; t++) th.emplace_back(route, t);
+        for (uint32_t t = 0; t < NT; t++) th.emplace_back(route, t);
         for (auto &x : th) x.join();
         th.clear();
-        for (uint32_t t = 0; t < T; t++) th.emplace_back(work, t);
+        // One file can be a fifth of the output (unknown/unknown/unknown-unknown/unknown.fastq takes every unmatched read) and
+        // a file is one thread's work: there are several shards per thread, handed out heaviest first, so that the thread
+        // that draws the big file does little else.
+        std::vector<std::pair<uint64_t, uint32_t>> load(T);
+        for (uint32_t t = 0; t < T; t++) {
+            uint64_t c = 0;
+            for (uint32_t slice = 0; slice < P; slice++) c += w->route[(size_t)slice * T + t].size();
+            load[t] = {c, t};
+        }
+        std::sort(load.begin(), load.end(), [](const std::pair<uint64_t, uint32_t> &x, const std::pair<uint64_t, uint32_t> &y) {
+            return x.first != y.first ? x.first > y.first : x.second < y.second; });
+        std::atomic<uint32_t> next(0);
+        const double t1 = now();
+        for (uint32_t t = 0; t < NT; t++)
+            th.emplace_back([&, t] {
+                const double a = now();
+                for (uint32_t k = next.fetch_add(1); k < T; k = next.fetch_add(1)) work(load[k].second);
+                took[t] = now() - a;
+            });
         for (auto &x : th) x.join();
+        if (dbg) {
+            const double t2 = now();
+            std::string line;
+            char tmp[64];
+            double sum = 0, mx = 0;
+            for (uint32_t t = 0; t < NT; t++) { sum += took[t]; mx = std::max(mx, took[t]); snprintf(tmp, sizeof(tmp), " %.1f", took[t] * 1e3); line += tmp; }
+            fprintf(stderr, "[smx writer] route %.1f ms, shards %.1f ms (max %.1f, mean %.1f; heaviest shard %llu of %u entries):%s\n",
+                    (t1 - t0) * 1e3, (t2 - t1) * 1e3, mx * 1e3, sum / NT * 1e3, (unsigned long long)load[0].first, n_reads + n_extra, line.c_str());
+        }
     }
     for (uint32_t t = 0; t < T; t++)
         if (w->shards[t].rc) return smx_set_error(w->shards[t].rc, "%s", errs[t].c_str());
@@ -1156,9 +1288,13 @@ int smx_writer_close(smx_writer *w) {
     int err = 0;
     {   // every shard flushes its own files: the tail of the run is as parallel as the rest
         std::vector<std::thread> th;
-        for (size_t t = 1; t < w->shards.size(); t++)
-            th.emplace_back([w, t] { for (auto &f : w->shards[t].files) smx_writer::flush(w->shards[t], f); });
-        if (!w->shards.empty()) for (auto &f : w->shards[0].files) smx_writer::flush(w->shards[0], f);
+        std::atomic<size_t> next(0);
+        auto drain = [&] {
+            for (size_t t = next.fetch_add(1); t < w->shards.size(); t = next.fetch_add(1))
+                for (auto &f : w->shards[t].files) smx_writer::flush(w->shards[t], f);
+        };
+        for (int t = 1; t < io_threads(); t++) th.emplace_back(drain);
+        drain();
         for (auto &x : th) x.join();
     }
     for (auto &sh : w->shards) if (!err) err = sh.first_errno;

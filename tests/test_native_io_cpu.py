@@ -377,3 +377,30 @@ def test_writer_reverse_complement_every_length_and_letter(tmp_path):
         exp += f"@{rid} 0,0,0,0 pool=P primers=F+R s\n{reverse_complement(s)[a:e]}\n+\n{q[::-1][a:e]}\n"
     assert (tmp_path / "o/full/P/F-R/s.fastq").read_text() == exp
     assert (tmp_path / "o/full/P/s.fastq").read_text() == exp
+
+
+@pytest.mark.parametrize("pos", [3, 15, 16, 17, 40, 63])
+@pytest.mark.parametrize("ch", [" ", "\t"])
+def test_white_space_inside_a_sequence_line_leaves_the_fast_engine(tmp_path, pos, ch, monkeypatch):
+    """The strict parser checks every sequence line for white space 16 bytes at a time (smx_io.cpp has_space): a blank
+    anywhere in the line must hand the file to the general engine, i.e. give what the copying path gives."""
+    from specimux_amd.native_io import Reader
+    seq = "ACGTTGCAAC" * 7
+    recs = [("a", seq, "I" * 70), ("b", seq[:pos] + ch + seq[pos + 1:], "J" * 70), ("c", seq[::-1], "K" * 70)]
+    fq = tmp_path / "blank.fastq"
+    fq.write_text("".join(f"@{i}\n{s}\n+\n{q}\n" for i, s, q in recs))
+
+    def read_all():
+        r = Reader(os.fspath(fq))
+        out = []
+        while True:
+            b = r.next_batch(100)
+            if b is None:
+                return out
+            out += [b.record(i) for i in range(len(b))]
+    got = read_all()
+    monkeypatch.setenv("SMX_IO_NO_MMAP", "1")
+    assert got == read_all()
+    exp, _ = O.read_sequences(os.fspath(fq))     # the oracle's line-based parser (Bio.SeqIO semantics)
+    assert got == [tuple(r) for r in exp]
+    assert [g[0] for g in got] == ["a", "b", "c"] and got[0] == recs[0] and got[2] == recs[2]

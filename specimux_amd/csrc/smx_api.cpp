@@ -155,6 +155,7 @@ struct smx_panel {
     // for the nitems alignments the match words flag; a tile that needs more goes on the overflow list and is redone by a
     // dense launch (R, lds) right behind the compact one.  nitems == 0: off.
     int Rc = 0, nitems = 0, blocks_per_cu_c = 1;
+    int env_stream_slots = 0;
     int share = 1;      // smx_panel_set_streams: batches the caller keeps in flight on as many streams
     size_t lds_c = 0;
     DevBuf ovf[SMX_MAX_STREAMS];             // per stream slot: overflow list, one entry per compact tile
@@ -301,6 +302,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     P->env_force_slots = getenv("SMX_FORCE_SLOTS") != nullptr;
     P->env_debug_overflow = getenv("SMX_DEBUG_OVERFLOW") != nullptr;
     P->env_debug = getenv("SMX_DEBUG") != nullptr;
+    if (const char *e = getenv("SMX_STREAM_SLOTS")) P->env_stream_slots = atoi(e);
     h.bs_m = bm[0];
     if (h.pfmin != 0 && h.pfmin < 2) { delete P; return fail(SMX_ERR_UNSUPPORTED, "prefilter min length %d < 2: disable the prefilter", h.pfmin); }
     if (h.bmax + h.kidx > 200) { delete P; return fail(SMX_ERR_UNSUPPORTED, "barcode length + k too large"); }
@@ -356,23 +358,25 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     // (6R vs 4R) and wins for panels with many primers (measured on the 8-primer panel: R = 32 x 3 beats R = 16 x 4 by 7 %,
     // R = 64 x 2 loses 45 %).  SMX_TILE_R / SMX_LDS_BUDGET override for tuning experiments.
     const bool budget_forced = getenv("SMX_LDS_BUDGET") != nullptr;
-    size_t budget = 40 * 1024;
+    auto lds_blocks = [](size_t need) { return (int)(SMX_LDS_POOL / ((need + 511) & ~(size_t)511)); };   // workgroups of `need` bytes a CU holds
+    size_t budget = (SMX_LDS_POOL / 4) & ~(size_t)511;
     if (budget_forced) budget = (size_t)atol(getenv("SMX_LDS_BUDGET"));
     int rmax = 64;
     if (const char *e = getenv("SMX_TILE_R")) rmax = std::max(1, std::min(64, atoi(e)));
     const int npmeta = 5 * NP + 1 + h.n_pbc + NB + 3 * NPAIR;
+    const int tails = h.trim == SMX_TRIM_TAILS ? 1 : 0;   // the per-entry extent array of the lean tails kernel (BSV 3)
     for (int slots = 0; slots < 2; slots++) {
         auto pick = [&](size_t bud, int *Rout, size_t *need_out) {
             for (int R = rmax; R >= 1; R >>= 1) {
                 size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, slots,
-                                                  h.bs_ok, 0, 2 * NPAIR);
+                                                  h.bs_ok, 0, 2 * NPAIR, tails);
                 if (need <= bud || R == 1) { *Rout = R; *need_out = need; return; }
             }
         };
         int R4 = 1, R3 = 1;
         size_t n4 = 0, n3 = 0;
         pick(budget, &R4, &n4);
-        if (!budget_forced) pick((160 * 1024) / 3 - 512, &R3, &n3);
+        if (!budget_forced) pick((SMX_LDS_POOL / 3) & ~(size_t)511, &R3, &n3);
         const bool three = !budget_forced && !slots && R3 > R4;   // (the slots kernel measured 2.5 % slower that way)
         if (slots) { P->R_slots = three ? R3 : R4; P->lds_slots = three ? n3 : n4; }
         else { P->R = three ? R3 : R4; P->lds = three ? n3 : n4; }
@@ -387,20 +391,30 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
         int items = 256;
         if (const char *e = getenv("SMX_COMPACT_ITEMS")) items = std::max(2 * NP, std::min(256, atoi(e)));
         if (P->pre_ok && !(ce && atoi(ce) == 0) && (P->R < 64 || getenv("SMX_COMPACT_ITEMS"))) {
-            auto need_c = [&](int R) { return smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, 0, h.bs_ok, items, 2 * NPAIR); };
+            auto need_c = [&](int R) { return smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, 0, h.bs_ok, items, 2 * NPAIR, tails); };
             int best_R = 0, best_blocks = 0;
             size_t best_need = 0;
             for (int R = 64; R >= 8; R -= 8) {
                 const size_t need = need_c(R);
-                if (need > 160 * 1024 - 2048) continue;
-                const int blocks = (int)std::min<size_t>(4, (160 * 1024 - 1024) / (need + 512));
+                if (need > SMX_LDS_POOL) continue;
+                const int blocks = std::min(4, lds_blocks(need));
                 if (blocks < 3) continue;   // two workgroups per CU lose more to exposed latency than their larger tiles win back
                                             // (measured: 8-primer panel, -l 160: R = 64 x 2 is 40 % slower than R = 40 x 3)
                 if (R * blocks > best_R * best_blocks) { best_R = R; best_blocks = blocks; best_need = need; }
             }
+            // a tile size that has a default-flags instantiation wins over a larger generic one (wide-window stress shape:
+            // 32-read tiles on `SP = 3` 1.11 ms per 10^6 reads, 48-read tiles on the generic compact kernel 1.15)
+            for (int R = 64; R >= 8; R -= 8) {
+                const size_t need = need_c(R);
+                if (need > SMX_LDS_POOL || lds_blocks(need) < 3) continue;
+                if (smx_demux_sp_query(&h, P->use64, 0, 1, R, items, 1) != 0) {
+                    if (R != best_R) { best_R = R; best_blocks = std::min(4, lds_blocks(need)); best_need = need; }
+                    break;
+                }
+            }
             if (const char *e = getenv("SMX_COMPACT_R")) { best_R = std::max(1, std::min(64, atoi(e))); best_need = need_c(best_R); best_blocks = 1; }
-            const int dense_blocks = (int)std::min<size_t>(4, (160 * 1024 - 1024) / (P->lds + 512));
-            if (best_R > 0 && (best_R * best_blocks > P->R * dense_blocks || getenv("SMX_COMPACT_ITEMS") || getenv("SMX_COMPACT_R"))) {
+            const int dense_blocks = std::min(4, lds_blocks(P->lds));
+            if (best_R > 0 && (best_R * best_blocks >= P->R * dense_blocks || getenv("SMX_COMPACT_ITEMS") || getenv("SMX_COMPACT_R"))) {
                 P->Rc = best_R; P->nitems = items; P->lds_c = best_need;
             }
         }
@@ -669,7 +683,11 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     uint32_t tiles = (n_reads + R - 1) / R;
     // (batches in flight on several streams share the CUs' workgroup slots: each demux launch takes its part of them, so
     // that the next batch's memory-bound and VALU-bound prescan kernels run beside this batch's latency-bound demux kernel)
-    auto slots_of = [&](int blocks) { return (uint32_t)(P->n_cu * std::max(1, (blocks + P->share - 1) / P->share)); };
+    auto slots_of = [&](int blocks) {
+        int per = std::max(1, (blocks + P->share - 1) / P->share);
+        if (P->env_stream_slots > 0 && P->share > 1) per = std::min(blocks, P->env_stream_slots);   // tuning hook (SMX_STREAM_SLOTS)
+        return (uint32_t)(P->n_cu * per);
+    };
     int grid = (int)std::min<uint32_t>(tiles, slots_of(use_slots ? P->blocks_per_cu_slots : P->blocks_per_cu));
     int e;
     if (compact) {

@@ -6,6 +6,9 @@
 #include "smx.h"
 #include "smx_prescan_core.h"
 
+// LDS a CU of gfx950 gives to workgroups (in 512-byte granules): measured, tools/ubench/lds_residency.hip
+#define SMX_LDS_POOL ((size_t)159744)
+
 namespace smx {
 
 // Text alphabet of the kernels: 16 codes.  Code 15 ("other") never matches any pattern character.
@@ -78,8 +81,9 @@ int smx_prescan_set_lds_limit(size_t bytes);
 int smx_prescan_occupancy(int S, int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d);
 int smx_prescan_transpose_threads(int S);
 size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta, int kidx,
-                           int slots, int bs, int nitems, int ncand);
+                           int slots, int bs, int nitems, int ncand, int tails);
 int smx_set_demux_lds_limit(int use64, size_t bytes);
+int smx_demux_sp_query(const smx::DevPanel *P, int use64, int use_slots, int cm, int R, int nitems, int have_prescan);
 int smx_query_occupancy(const smx::DevPanel *P, int use64, int use_slots, int cm, int R, int nitems, size_t lds_bytes,
                         int *blocks_per_cu, int have_prescan);
 int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,

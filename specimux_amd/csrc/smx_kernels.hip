@@ -107,6 +107,14 @@ __device__ __forceinline__ BcGeom bc_geom(int L, int base, int bstart) {
 
 // ------------------------------------------------------------------------------------------------
 // LDS-resident per (read, primer, end) record.
+// Tile geometry of the two-primer default-flags kernel (SP = 2): reads per tile, and the resident workgroups per CU it is
+// built for.  Five: its tile is 31.5 KB of LDS (five of them fit a CU: tools/ubench/lds_residency.hip) and the register
+// allocator is held to 96 VGPRs (8 values spilled).  Measured: 56-read tiles at four per CU 0.255 ms, at five 0.228 ms.
+#ifndef SMX_SP2_R
+#define SMX_SP2_R 64
+#define SMX_SP2_WG 5
+#endif
+
 struct HitL {
     int tail_end;       // reference coord: max optimal end over all within-k barcodes (slots mode), valid if bbest >= 0
     short nloc;
@@ -146,10 +154,15 @@ struct EntL {   // one optimal primer location of one searched hit = one barcode
 };
 static_assert(sizeof(EntL) == 12, "EntL layout");
 
+// the scorer looks at the candidates of matched alignments only (panels with more than two primer pairs)
+__host__ __device__ inline bool layout_cfilt(int H, int ncand) { return H <= 64 && ncand <= 64 && ncand > 4; }
+__host__ __device__ inline bool layout_tie_in_rec(int MBW, int slots, int tails) { return MBW == 1 && !slots && !tails; }
+#define OCNT_NA 0x8000
+
 template <typename PW>
 __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, int maxB, int need_starts,
                                                     int npmeta, int kidx, int slots, int bs, int ncand, int cap_hits = 0,
-                                                    int cap_ents = 0, int nitems = 0) {
+                                                    int cap_ents = 0, int nitems = 0, int tails = 1) {
     // nitems > 0: compact mode.  The tile keeps per-alignment state (hit record, end mask, scan slots) for at most nitems
     // of its R * H alignments -- the ones the prescan's match words flag -- plus one shared "no match" record; hmap maps
     // (read, alignment) to its record.  Panels with many primers spend most of their LDS on alignments that never match.
@@ -185,13 +198,17 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.codes = o; o += R * 2 * t.CS;
     t.namask = o; o += R * 2 * MW * 4;         // per code row: bit j set = code[j] is not A/C/G/T
     t.lens = o;  o += 2 * R * 4;               // double-buffered: the next tile is encoded while this one is scored
-    t.ocnt = o;  o += 2 * R * 4;               // per read: forward votes | reverse votes << 16; double-buffered
-    t.rflag = o; o += 2 * R * 4;               // per read: 1 = a window holds something other than upper-case ACGT: scalar primer scan; double-buffered
+    t.ocnt = o;  o += 2 * R * 4;               // per read: forward votes | OCNT_NA (a window holds something other than upper-case
+                                               // ACGT: scalar primer scan) | reverse votes << 16; double-buffered
+    t.rflag = o;                               // (round 3: the flag is bit 15 of ocnt, no region of its own)
     o = (o + 7) & ~7;
-    t.pmask = o; o += R * 8;                   // per read: bit h = alignment h found its primer (scorer: which candidates to look at)
+    const bool cf = layout_cfilt(H, ncand);
+    t.pmask = o; o += cf ? R * 8 : 0;          // per read: bit h = alignment h found its primer (scorer: which candidates to look at)
     o = (o + 15) & ~15;
     t.hits = o;  o += (t.NI + sentinel) * (int)sizeof(HitL);
-    t.tiem = o;  o += (t.NI + sentinel) * t.MBW * 4;
+    // one tie-mask word per record and nothing else wanting HitL::tail_end (it belongs to slots mode and --trim tails): the word
+    // lives there, no array of its own
+    t.tiem = o;  o += layout_tie_in_rec(t.MBW, slots, tails) ? 0 : (t.NI + sentinel) * t.MBW * 4;
     t.clist = o; o += nitems > 0 ? ((t.NI + 1) & ~1) * 2 : 0;       // record -> read * H + alignment
     // time-shared regions: {location entries} are dead after the barcode scan -> staged result records;
     // {primer end masks, scans, queue} are dead once the scorer starts -> its per-(read, candidate) trim shifts (Q8)
@@ -201,16 +218,17 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
         o = (o + 15) & ~15;
         t.ents = t.opsL = o; o += c > d ? c : d;
     }
-    t.etail = o; o += (bs && !slots) ? t.CAPE * 4 : 0;   // --trim tails on the lean path: end of the kept alignment per entry
+    t.etail = o; o += (bs && !slots && tails) ? t.CAPE * 4 : 0;   // --trim tails on the lean path (BSV == 3): end of the kept alignment per entry
     t.masks = t.emit = o; o += t.NI * MW * 4;
-    t.offsA = o; o += (t.NI + 1) * 4;
-    t.offsB = o; o += (t.NI + 1) * 4;
+    o = (o + 3) & ~3;
+    t.offsA = o; o += ((t.NI + 2) & ~1) * 2;   // 16-bit scans: a tile has at most NI * S < 65536 locations
+    t.offsB = o; o += ((t.NI + 2) & ~1) * 2;   // (>= 16 bytes: the one-round path parks four wave sums here)
     t.queue = o; o += ((t.NI + 1) & ~1) * 2;
     if (o < t.emit + R * ncand * 4) o = t.emit + R * ncand * 4;
     o = (o + 7) & ~7;
     t.hmap = o;  o += nitems > 0 ? ((R * H + 1) & ~1) * 2 : 0;     // (read, alignment) -> record; t.NI = the shared "no match" record
     o = (o + 7) & ~7;
-    t.hcand = o; o += (H <= 64 ? H : 0) * 8;   // per alignment: the candidates (pair * 2 + orientation) it belongs to
+    t.hcand = o; o += cf ? H * 8 : 0;          // per alignment: the candidates (pair * 2 + orientation) it belongs to
     o = (o + 15) & ~15;
     t.ppeq = o;  o += t.NPs * 16 * (int)sizeof(PW);
     t.prpeq = o; o += (need_starts ? t.NPs * 16 * (int)sizeof(PW) : 0);
@@ -223,7 +241,7 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
 }
 
 // exclusive scan of a[0..n) in LDS by ONE wave (all 64 lanes of it call this); a[n] = total.
-__device__ inline void wave_exclusive_scan(int *a, int n) {
+__device__ inline void wave_exclusive_scan(unsigned short *a, int n) {
     int lane = threadIdx.x & 63;
     int chunk = (n + 63) / 64;
     int lo = lane * chunk, hi = lo + chunk < n ? lo + chunk : n;
@@ -235,8 +253,8 @@ __device__ inline void wave_exclusive_scan(int *a, int n) {
         if (lane >= d) incl += v;
     }
     int run = incl - sum;
-    for (int i = lo; i < hi; i++) { int v = a[i]; a[i] = run; run += v; }
-    if (lane == 63) a[n] = incl;
+    for (int i = lo; i < hi; i++) { int v = a[i]; a[i] = (unsigned short)run; run += v; }
+    if (lane == 63) a[n] = (unsigned short)incl;
 }
 
 // loc_ord-th (0-based) optimal end at or after jstar in a location bitmask
@@ -512,7 +530,8 @@ struct ReadCtx {
     const DevPanel *P;
     LPanel LP;
     const HitL *hits;          // this read's H records (compact mode: the tile's records, indexed through hmap)
-    const unsigned *tiem;      // the records' MBW tie bitmasks each (barcodes at the best distance)
+    const unsigned *tiem;      // the records' tie bitmasks (barcodes at the best distance): word w of record i = tiem[i * tstr + w]
+    int tstr;
     const unsigned short *hmap;   // compact mode: this read's alignment -> record; nullptr: record = alignment
     const unsigned long long *hcand;   // per alignment: bitmask of the candidates it belongs to; nullptr: look at every candidate
     int trim, derep;              // the panel's --trim / --dereplicate (compile-time constants in the default-flags kernel)
@@ -583,7 +602,7 @@ __device__ inline int next_tied(const ReadCtx &c, int h, int from) {
     int p = h >> 1;
     int nb = c.LP.pbc_off[p + 1] - c.LP.pbc_off[p];
     if (from >= nb) return -1;
-    const unsigned *tm = c.tiem + c.rec(h) * c.MBW;
+    const unsigned *tm = c.tiem + c.rec(h) * c.tstr;
     int w = from >> 5;
     unsigned word = tm[w] & (~0u << (from & 31));
     for (;;) {
@@ -1130,11 +1149,13 @@ struct DemuxTile {
     unsigned *bpeq, *bsre;
     unsigned char *lut, *codes;
     unsigned *namask;
-    int *lensL, *ocnt, *rflag;
+    int *lensL, *ocnt;
     HitL *hits;
-    unsigned *masks, *tiem, *bres, *dmask;
+    unsigned *masks, *tieb, *bres, *dmask;   // tieb[i * tstr + w]: tie-mask word w of record i
+    int tstr;
     EntL *ents;
-    int *etail, *offsA, *offsB;
+    int *etail;
+    unsigned short *offsA, *offsB;
     unsigned short *queue;
     int *cumL;
     smx_op *opsL;
@@ -1149,7 +1170,6 @@ struct DemuxTile {
     bool live;                  // false: nothing to do for `cur` (none yet, or a compact tile left to the redo launch)
     unsigned popped;
     int *lensC, *ocntC;
-    const int *rflagC;
     bool prelisted;
     int nq, nE_pre;
 
@@ -1206,7 +1226,7 @@ struct DemuxTile {
         lds = lds_; P = P_; windows = windows_; lens = lens_; n_reads = n_reads_; ops = ops_; extra = extra_; extra_cap = extra_cap_;
         n_extra = n_extra_; counts = counts_; dbg_hits = dbg_hits_; tile_counter = tile_counter_; pre = pre_; aux = aux_;
         // SP = 3: SP = 1 with search_len 160 and 32-read tiles (the wide-window stress shape of a many-primer panel)
-        R = SP == 3 ? 32 : (sp ? 64 : R_arg);   // (the specialised kernels are only launched with these tile sizes)
+        R = SP == 3 ? 32 : (SP == 2 ? SMX_SP2_R : (sp ? 64 : R_arg));   // (the specialised kernels are only launched with these tile sizes)
         // SP = 2: SP = 1 for a panel with two primers (one forward, one reverse: a single amplicon) -- the tile's 256
         // alignments are one per lane, every LDS offset in front of the panel tables is a constant
         NP = SP == 2 ? 2 : P->NP; NB = P->NB; S = SP == 3 ? 160 : (sp ? 80 : P->S); H = 2 * NP; MW = (S + 31) / 32; maxB = P->maxB;
@@ -1218,8 +1238,9 @@ struct DemuxTile {
         dbg_bdist = SP != 0 ? nullptr : dbg_bdist_arg;
         use_bs = SP != 0 ? 1 : ((BSV != 0 && P->bs_ok && !use_slots) ? 1 : 0);
         ncand = 2 * NPAIR;
+        const int tails = sp ? 0 : (P->trim == SMX_TRIM_TAILS ? 1 : 0);
         T = make_layout<PW>(NP, NB, S, R, maxB, need_starts, npmeta, sp ? 3 : P->kidx, use_slots, P->bs_ok, ncand,
-                            sp ? 0 : P->cap_hits, sp ? 0 : P->cap_ents, (sp && CM == 1) ? 256 : aux.nitems);
+                            sp ? 0 : P->cap_hits, sp ? 0 : P->cap_ents, (sp && CM == 1) ? 256 : aux.nitems, tails);
         ppeq = (PW *)(lds + T.ppeq);        // [code][primer], stride NPs
         prpeq = (PW *)(lds + T.prpeq);
         bpeq = (unsigned *)(lds + T.bpeq);   // [code][barcode], stride NBs
@@ -1229,16 +1250,16 @@ struct DemuxTile {
         namask = (unsigned *)(lds + T.namask);
         lensL = (int *)(lds + T.lens);
         ocnt = (int *)(lds + T.ocnt);
-        rflag = (int *)(lds + T.rflag);
         hits = (HitL *)(lds + T.hits);
         masks = (unsigned *)(lds + T.masks);
-        tiem = (unsigned *)(lds + T.tiem);
+        if (layout_tie_in_rec(T.MBW, use_slots, tails)) { tieb = (unsigned *)(lds + T.hits); tstr = (int)(sizeof(HitL) / 4); }   // HitL::tail_end is word 0
+        else { tieb = (unsigned *)(lds + T.tiem); tstr = sp ? 1 : T.MBW; }
         bres = (unsigned *)(lds + T.bres);
         dmask = (unsigned *)(lds + T.dmask);   // lean mode: [hit in round][distance][MBW] barcode bitmasks
         ents = (EntL *)(lds + T.ents);
         etail = (int *)(lds + T.etail);     // BSV == 3 only
-        offsA = (int *)(lds + T.offsA);    // exclusive scan of searched locations per hit
-        offsB = (int *)(lds + T.offsB);    // exclusive scan of searched hits (rank)
+        offsA = (unsigned short *)(lds + T.offsA);    // exclusive scan of searched locations per hit
+        offsB = (unsigned short *)(lds + T.offsB);    // exclusive scan of searched hits (rank)
         queue = (unsigned short *)(lds + T.queue);   // rank -> hit
         cumL = (int *)(lds + T.emit);      // scorer: [read][candidate] accumulated trim shift
         opsL = (smx_op *)(lds + T.opsL);
@@ -1247,7 +1268,7 @@ struct DemuxTile {
         clist = (unsigned short *)(lds + T.clist);   // compact mode: record -> read * H + alignment
         pmask = (unsigned long long *)(lds + T.pmask);   // per read: alignments with a primer match
         hcand = (unsigned long long *)(lds + T.hcand);   // per alignment: its candidates
-        cfilt = H <= 64 && NPAIR * 2 <= 64 && NPAIR * 2 > 4;   // the scorer looks at matched alignments' candidates only
+        cfilt = layout_cfilt(H, NPAIR * 2);   // the scorer looks at matched alignments' candidates only
         tid = threadIdx.x;
         wave = tid >> 6;
         if (redo && tile_counter[1] == 0) {   // the usual redo launch: nothing on the list (every workgroup sees the same count:
@@ -1304,14 +1325,14 @@ struct DemuxTile {
             }
         }
         if (tid < 12) aggr[tid] = 0;
-        for (int i = tid; i < R; i += NT) pmask[i] = 0ull;
+        if (cfilt) for (int i = tid; i < R; i += NT) pmask[i] = 0ull;
         if (cfilt) for (int i = tid; i < H; i += NT) hcand[i] = 0ull;
         if (cmode && tid == 0) {   // the shared record of every alignment that is not flagged: what the primer scan writes for "no match"
             HitL hn;
             hn.tail_end = -1; hn.nloc = 0; hn.ntied = 0; hn.first_tied = -1; hn.pdist = -1; hn.bbest = -2; hn.jstar = 0; hn.fs_j = 0;
             hn.flags = 0; hn.pad = 0;
             hits[T.NI] = hn;
-            for (int w = 0; w < T.MBW; w++) tiem[T.NI * T.MBW + w] = 0;
+            for (int w = 0; w < T.MBW; w++) tieb[T.NI * tstr + w] = 0;
         }
         __syncthreads();
         if (cfilt)
@@ -1488,7 +1509,7 @@ struct DemuxTile {
                 for (int u = 0; u < 4; u++) {
                     const int i = i0 + u * NT;
                     if (i < nh) {
-                        const bool flagged = (mw[u] & 1u) || rflagC[divH(i)] != 0;
+                        const bool flagged = (mw[u] & 1u) || (ocntC[divH(i)] & OCNT_NA) != 0;
                         int rec = T.NI;
                         if (flagged) {
                             const int sl = atomicAdd(&aggr[11], 1);
@@ -1508,7 +1529,7 @@ struct DemuxTile {
         if (!live) {
         } else if (pre != nullptr) {
             for (int item = tid; item < nI; item += NT) {
-                if (rflagC[divH(cmode ? (int)clist[item] : item)] == 0) primer_item(item, true);
+                if ((ocntC[divH(cmode ? (int)clist[item] : item)] & OCNT_NA) == 0) primer_item(item, true);
                 else fbq[atomicAdd(&aggr[10], 1)] = (unsigned short)item;
             }
             __syncthreads();
@@ -1530,7 +1551,7 @@ struct DemuxTile {
         const int dn = cmode ? (int)clist[item] : item;
         int r = divH(dn), h = dn - __mul24(r, H), p = h >> 1, X = h & 1;
         int L = lensC[r];
-        int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
+        int f = ocntC[r] & 0x7FFF, rv = ocntC[r] >> 16;
         int ori = 3;   // bit0: as-read candidates allowed, bit1: reverse-complement candidates allowed
         if (preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
         bool filtered = (minlen != -1 && L < minlen) || (maxlen != -1 && L > maxlen);
@@ -1544,7 +1565,7 @@ struct DemuxTile {
             hl.bbest = -1;
             n = hl.nloc;
         }
-        for (int w = 0; w < MBW; w++) tiem[__mul24(item, MBW) + w] = 0;
+        for (int w = 0; w < MBW; w++) tieb[__mul24(item, tstr) + w] = 0;
         return n;
     }
     // the optimal locations of one searched hit -> entries e, e+1, ... (target start, prefilter verdict)
@@ -1618,7 +1639,7 @@ struct DemuxTile {
                 nE_pre = totE;
                 if (n > 0) {
                     queue[excl >> 16] = (unsigned short)item;
-                    if (BSV == 3) offsA[item] = (int)(excl & 0xFFFFu);   // first entry of the hit (tails pass)
+                    if (BSV == 3) offsA[item] = (unsigned short)(excl & 0xFFFFu);   // first entry of the hit (tails pass)
                     list_entries(item, (int)(excl >> 16), (int)(excl & 0xFFFFu));
                 }
                 if (use_slots) { for (int i = tid; i < (nq << logG); i += NT) bres[i] = 0xFFFFFFFFu; }
@@ -1627,17 +1648,17 @@ struct DemuxTile {
             } else {   // several rounds: hand the scans over to the general code below
                 __syncthreads();   // wsum (in offsB) has been read by everyone
                 if (item < nI) {
-                    offsA[item] = (int)(excl & 0xFFFFu);
-                    offsB[item] = (int)(excl >> 16);
+                    offsA[item] = (unsigned short)(excl & 0xFFFFu);
+                    offsB[item] = (unsigned short)(excl >> 16);
                     if (n > 0) queue[excl >> 16] = (unsigned short)item;
                 }
-                if (tid == 0) { offsA[nI] = totE; offsB[nI] = nq; }
+                if (tid == 0) { offsA[nI] = (unsigned short)totE; offsB[nI] = (unsigned short)nq; }
                 __syncthreads();
             }
         } else {
             for (int item = tid; item < nI; item += NT) {
                 int n = locations_needed(item);
-                offsA[item] = n;
+                offsA[item] = (unsigned short)n;
                 offsB[item] = n > 0 ? 1 : 0;
             }
             __syncthreads();
@@ -1761,7 +1782,7 @@ struct DemuxTile {
                     if (nt) {
                         HitL &hl = hits[item];
                         hl.bbest = (signed char)d; hl.ntied = (short)nt; hl.first_tied = (short)first;
-                        for (int w = 0; w < MBW; w++) tiem[item * MBW + w] = dm[d * MBW + w];
+                        for (int w = 0; w < MBW; w++) tieb[item * tstr + w] = dm[d * MBW + w];
                         break;
                     }
                 }
@@ -1844,8 +1865,8 @@ struct DemuxTile {
                     HitL &hl = hits[item];
                     hl.bbest = (signed char)dmin; hl.ntied = (short)__popcll(gm); hl.first_tied = (short)first;
                     hl.tail_end = tail;
-                    tiem[item * MBW] = (unsigned)gm;
-                    if (MBW > 1) tiem[item * MBW + 1] = (unsigned)(gm >> 32);
+                    tieb[item * tstr] = (unsigned)gm;
+                    if (MBW > 1) tieb[item * tstr + 1] = (unsigned)(gm >> 32);
                 }
             }
         } else
@@ -1878,7 +1899,7 @@ struct DemuxTile {
                 if ((v >> 24) == best) {
                     if (ntied == 0) first = i;
                     ntied++;
-                    tiem[item * MBW + (i >> 5)] |= 1u << (i & 31);
+                    tieb[item * tstr + (i >> 5)] |= 1u << (i & 31);
                 }
             }
             hl.bbest = (signed char)best; hl.ntied = (short)ntied; hl.first_tied = (short)first;
@@ -1932,7 +1953,7 @@ struct DemuxTile {
     __device__ __forceinline__ void zero_for_next() {
         // the encode target buffers: namask is OR-ed into, the next tile's orientation votes are counted up
         for (int i = tid; i < R * 2 * MW; i += NT) namask[i] = 0;
-        for (int i = tid; i < R; i += NT) { ocnt[(par ^ 1) * R + i] = 0; rflag[(par ^ 1) * R + i] = 0; }
+        for (int i = tid; i < R; i += NT) ocnt[(par ^ 1) * R + i] = 0;
         if (live) for (int i = tid; i < nr * ncand; i += NT) cumL[i] = 0;   // (the masks / scan arrays it overlays are dead by now)
         if (tid == 0) { aggr[9] = (int)popped; aggr[11] = 0; }
         __syncthreads();
@@ -1950,7 +1971,7 @@ struct DemuxTile {
         if (r < nr) {
             int L = lensC[r];
             bool filtered = (minlen != -1 && L < minlen) || (maxlen != -1 && L > maxlen);
-            const unsigned long long pm_r = pmask[r];   // (the lanes sharing a read sit in one wave: all have read it
+            const unsigned long long pm_r = cfilt ? pmask[r] : 0ull;   // (the lanes sharing a read sit in one wave: all have read it
             if (cfilt && sub == 0) pmask[r] = 0ull;     //  when the lead lane clears it for the next tile)
             if (sub == 0) atomicAdd(&aggr[0], 1);
             if (filtered) {
@@ -1967,12 +1988,13 @@ struct DemuxTile {
                 c.P = P; c.LP = LP; c.MBW = MBW; c.L = L; c.S = S;
                 c.trim = sp ? (int)SMX_TRIM_BARCODES : P->trim; c.derep = sp ? (int)SMX_DEREP_BEST : P->derep;
                 c.npair = NPAIR;
-                if (cmode) { c.hits = hits; c.tiem = tiem; c.hmap = hmap + r * H; }
-                else { c.hits = hits + r * H; c.tiem = tiem + r * H * MBW; c.hmap = nullptr; }
+                c.tstr = tstr;
+                if (cmode) { c.hits = hits; c.tiem = tieb; c.hmap = hmap + r * H; }
+                else { c.hits = hits + r * H; c.tiem = tieb + r * H * tstr; c.hmap = nullptr; }
                 c.hcand = cfilt ? hcand : nullptr;
                 c.pm = pm_r;
                 c.g = end_geom(L, S);
-                int f = ocntC[r] & 0xFFFF, rv = ocntC[r] >> 16;
+                int f = ocntC[r] & 0x7FFF, rv = ocntC[r] >> 16;
                 int ori = 3;
                 if (preorient) { if (f > 0 && rv == 0) ori = 1; else if (rv > 0 && f == 0) ori = 2; }
                 c.set_live(ori);
@@ -2020,14 +2042,14 @@ struct DemuxTile {
                         unsigned cd = lut[256 + ch];
                         int j = Sp - 1 - pos;
                         rowA[j] = (unsigned char)cd;
-                        if (cd > 3) { atomicOr(&namask[(r * 2 + 0) * MW + (j >> 5)], 1u << (j & 31)); rflag[(par ^ 1) * R + r] = 1; }
+                        if (cd > 3) { atomicOr(&namask[(r * 2 + 0) * MW + (j >> 5)], 1u << (j & 31)); atomicOr(&ocnt[(par ^ 1) * R + r], OCNT_NA); }
                     }
                 } else if (pos < 2 * S) { // tail byte j -> B[j]
                     int j = pos - S;
                     if (j < Sp) {
                         unsigned cd = lut[ch];
                         rowB[j] = (unsigned char)cd;
-                        if (cd > 3) { atomicOr(&namask[(r * 2 + 1) * MW + (j >> 5)], 1u << (j & 31)); rflag[(par ^ 1) * R + r] = 1; }
+                        if (cd > 3) { atomicOr(&namask[(r * 2 + 1) * MW + (j >> 5)], 1u << (j & 31)); atomicOr(&ocnt[(par ^ 1) * R + r], OCNT_NA); }
                     }
                 }
             }
@@ -2120,7 +2142,7 @@ struct DemuxTile {
                 o.first_end = hl.pdist >= 0 ? (int)hl.jstar - g.j_lo + g.shift : -1;
                 o.bbest = hl.bbest; o.ntied = hl.ntied;
                 o.first_tied = (short)((hl.bbest >= 0) ? LP.pbc[LP.pbc_off[(item - r * H) >> 1] + hl.first_tied] : -1);
-                o.tail_end = hl.bbest >= 0 ? hl.tail_end : -1;
+                o.tail_end = (hl.bbest >= 0 && tstr != (int)(sizeof(HitL) / 4)) ? hl.tail_end : -1;   // (tie word in the slot: no extent kept)
                 o.flags = (int16_t)(hl.flags & 1);
                 dbg_hits[(size_t)(r0 + r) * H + (item - r * H)] = o;
             }
@@ -2153,7 +2175,6 @@ struct DemuxTile {
             nI = nh;          // alignments with a record: all of them, or (compact mode) the flagged ones
             live = have;
             lensC = lensL + par * R; ocntC = ocnt + par * R;
-            rflagC = rflag + par * R;
             if (timing) tacc[10] = clock64();
             if (have) {
                 phase2_primers();
@@ -2199,7 +2220,7 @@ struct DemuxTile {
 // ------------------------------------------------------------------------------------------------
 // BSV selects the barcode scan compiled into the kernel: see the comment in front of DemuxTile's template parameters above.
 template <typename PW, int NT, int BSV, int CM = 0, int SP = 0>   // NT = 256 threads per workgroup (tiles of up to 64 reads)
-__global__ __launch_bounds__(NT, 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
+__global__ __launch_bounds__(NT, SP == 2 ? SMX_SP2_WG : 4) void demux_kernel(DevPanel Pv, const uint8_t *__restrict__ windows,
                                                     const int32_t *__restrict__ lens, uint32_t n_reads, int R_arg,
                                                     smx_op *__restrict__ ops, smx_op *__restrict__ extra,
                                                     uint32_t extra_cap, uint32_t *n_extra,
@@ -2359,10 +2380,16 @@ int demux_sp(const smx::DevPanel *P, int use64, int bsv, int cm, int R, int nite
                        P->preorient && P->minlen == -1 && P->maxlen == -1 && !P->dbg_phase && !(P->no_sp & 1);
     if (!flags) return 0;
     if (P->S == 160 && R == 32 && cm == 1) return 3;                       // wide windows, compact 32-read tiles
-    if (P->S != 80 || R != 64) return 0;
-    return (cm == 0 && P->NP == 2 && P->NPAIR == 1 && !(P->no_sp & 2)) ? 2 : 1;
+    if (P->S != 80) return 0;
+    if (R == SMX_SP2_R && cm == 0 && P->NP == 2 && P->NPAIR == 1 && !(P->no_sp & 2)) return 2;
+    return R == 64 ? 1 : 0;
 }
 }  // namespace
+
+// which default-flags instantiation a launch with these parameters would get (0: the generic kernel)
+extern "C" int smx_demux_sp_query(const smx::DevPanel *P, int use64, int use_slots, int cm, int R, int nitems, int have_prescan) {
+    return demux_sp(P, use64, demux_bsv(P, use_slots), cm, R, nitems, have_prescan != 0);
+}
 
 extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int grid, size_t lds_bytes, void *stream,
                                 const uint8_t *d_windows, const int32_t *d_lens, uint32_t n_reads, smx_op *d_ops,
@@ -2389,9 +2416,9 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
 }
 
 extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta,
-                                      int kidx, int slots, int bs, int nitems, int ncand) {
-    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, ncand, 0, 0, nitems).total
-                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, ncand, 0, 0, nitems).total;
+                                      int kidx, int slots, int bs, int nitems, int ncand, int tails) {
+    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, ncand, 0, 0, nitems, tails).total
+                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, ncand, 0, 0, nitems, tails).total;
 }
 
 extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
@@ -2412,8 +2439,16 @@ extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {
 extern "C" int smx_query_occupancy(const smx::DevPanel *P, int use64, int use_slots, int cm, int R, int nitems, size_t lds_bytes,
                                    int *blocks_per_cu, int have_prescan) {
     const int bsv = demux_bsv(P, use_slots);
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm, R, nitems, have_prescan != 0)),
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, demux_fn(use64, bsv, cm, demux_sp(P, use64, bsv, cm, R, nitems, have_prescan != 0)),
                                                              256, lds_bytes);
+    // The API divides the CU's 163 840 bytes by the request.  The hardware hands LDS out in 512-byte granules from 159 744
+    // bytes (tools/ubench/lds_residency.hip: a 32 256-byte workgroup is resident four times, not five; 54 272 bytes twice,
+    // not three times): workgroups the grid counts on but the CU cannot hold would start after the tile queue has drained.
+    if (e == hipSuccess && lds_bytes > 0) {
+        const int fit = (int)(SMX_LDS_POOL / ((lds_bytes + 511) & ~(size_t)511));
+        if (*blocks_per_cu > fit) *blocks_per_cu = fit < 1 ? 1 : fit;
+    }
+    return (int)e;
 }
 
 extern "C" int smx_launch_align(void *stream, const unsigned long long *d_peq, const unsigned long long *d_rpeq, int m,

@@ -685,6 +685,9 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
     // that the next batch's memory-bound and VALU-bound prescan kernels run beside this batch's latency-bound demux kernel)
     auto slots_of = [&](int blocks) {
         int per = std::max(1, (blocks + P->share - 1) / P->share);
+        // two launches side by side must not claim more slots than the CU has: nothing of the next batch's prescan kernels
+        // would fit beside them (five slots, two streams: 3 + 3 measured 0.335 ms per step, 2 + 2 0.306-0.319)
+        if (P->share == 2 && per * 2 > blocks) per = std::max(1, blocks / 2);
         if (P->env_stream_slots > 0 && P->share > 1) per = std::min(blocks, P->env_stream_slots);   // tuning hook (SMX_STREAM_SLOTS)
         return (uint32_t)(P->n_cu * per);
     };

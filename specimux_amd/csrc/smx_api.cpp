@@ -120,7 +120,7 @@ struct smx_panel {
     smx::DevPanel hp;                 // scalar fields valid; pointers filled at upload
     std::vector<unsigned char> blob;  // host image of the device allocation
     size_t o_ppeq, o_prpeq, o_bpeq, o_lut, o_pm, o_pk, o_pdir, o_pfidx, o_pbc_off, o_pbc, o_bm, o_pair_f, o_pair_r,
-        o_pair_pool, o_bsre, o_pairrec = 0, o_specrec = 0;
+        o_pair_pool, o_bsre, o_bstab = 0, o_pairrec = 0, o_specrec = 0;
     int use64 = 0;
     bool env_no_lean_tails = false, env_force_slots = false, env_debug_overflow = false, env_debug = false;   // read once at create
     int R = 0;          // lean mode tile (no per-barcode slots)
@@ -294,6 +294,23 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
                         if (row >= bm[gb] || ((bpeq[gb * 16 + c] >> row) & 1u))
                             bsre[((((size_t)p * MBWh + (bi >> 5)) * 16 + row) * 16 + c)] |= 1u << (bi & 31);   // [primer][word][row][code]
             }
+    // primers with the same barcode list (the same kit in every pool) share one table: the 8-primer panel keeps 2 of 8 in LDS
+    std::vector<int> bs_tab(NP, 0);
+    {
+        const size_t tw = (size_t)16 * 16 * MBWh;
+        std::vector<unsigned> packed;
+        int nt = 0;
+        for (int p = 0; p < NP; p++) {
+            int found = -1;
+            for (int q = 0; q < nt && found < 0; q++)
+                if (std::equal(bsre.begin() + (size_t)p * tw, bsre.begin() + (size_t)(p + 1) * tw, packed.begin() + (size_t)q * tw)) found = q;
+            if (found < 0) { packed.insert(packed.end(), bsre.begin() + (size_t)p * tw, bsre.begin() + (size_t)(p + 1) * tw); found = nt++; }
+            bs_tab[p] = found;
+        }
+        if (getenv("SMX_NO_TABLE_SHARING")) { nt = NP; for (int p = 0; p < NP; p++) bs_tab[p] = p; }   // A/B and test hook
+        else bsre.swap(packed);
+        h.n_bstab = nt;
+    }
     h.bs_ok = bs_ok ? 1 : 0;
     if (const char *e = getenv("SMX_TEST_CAPS")) sscanf(e, "%d,%d", &h.cap_hits, &h.cap_ents);
     // the remaining test / A-B switches are read here, once: launches never look at the environment
@@ -349,6 +366,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
         P->o_pairrec = blob_add(B, pairrec); P->o_specrec = blob_add(B, specrec);
     }
     P->o_bsre = blob_add(B, bsre);
+    P->o_bstab = blob_add(B, bs_tab);
 
     P->use64 = maxm > 32 ? 1 : 0;
     // tile size: largest R in {64, 32, ...} whose LDS image lets 4 workgroups share a CU's 160 KiB
@@ -363,13 +381,13 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     if (budget_forced) budget = (size_t)atol(getenv("SMX_LDS_BUDGET"));
     int rmax = 64;
     if (const char *e = getenv("SMX_TILE_R")) rmax = std::max(1, std::min(64, atoi(e)));
-    const int npmeta = 5 * NP + 1 + h.n_pbc + NB + 3 * NPAIR;
+    const int npmeta = 6 * NP + 1 + h.n_pbc + NB + 3 * NPAIR;
     const int tails = h.trim == SMX_TRIM_TAILS ? 1 : 0;   // the per-entry extent array of the lean tails kernel (BSV 3)
     for (int slots = 0; slots < 2; slots++) {
         auto pick = [&](size_t bud, int *Rout, size_t *need_out) {
             for (int R = rmax; R >= 1; R >>= 1) {
                 size_t need = smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, slots,
-                                                  h.bs_ok, 0, 2 * NPAIR, tails);
+                                                  h.bs_ok, 0, 2 * NPAIR, tails, h.n_bstab);
                 if (need <= bud || R == 1) { *Rout = R; *need_out = need; return; }
             }
         };
@@ -391,7 +409,7 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
         int items = 256;
         if (const char *e = getenv("SMX_COMPACT_ITEMS")) items = std::max(2 * NP, std::min(256, atoi(e)));
         if (P->pre_ok && !(ce && atoi(ce) == 0) && (P->R < 64 || getenv("SMX_COMPACT_ITEMS"))) {
-            auto need_c = [&](int R) { return smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, 0, h.bs_ok, items, 2 * NPAIR, tails); };
+            auto need_c = [&](int R) { return smx_demux_lds_bytes(P->use64, NP, NB, h.S, R, maxB, h.need_starts, npmeta, h.kidx, 0, h.bs_ok, items, 2 * NPAIR, tails, h.n_bstab); };
             int best_R = 0, best_blocks = 0;
             size_t best_need = 0;
             for (int R = 64; R >= 8; R -= 8) {
@@ -562,6 +580,7 @@ static int ensure_device(smx_panel *P) {
     h.pairrec = (const smx::SpecRec *)(b + P->o_pairrec);
     h.specrec = (const smx::SpecRec *)(b + P->o_specrec);
     h.bs_re = (const unsigned *)(b + P->o_bsre);
+    h.bs_tab = (const int *)(b + P->o_bstab);
     if (std::max(std::max(P->lds, P->lds_slots), P->lds_c) > 64 * 1024) {
         const size_t lim = std::max(std::max(P->lds, P->lds_slots), P->lds_c);
         int rc = smx_set_demux_lds_limit(P->use64, lim);

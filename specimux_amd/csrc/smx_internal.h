@@ -47,6 +47,8 @@ struct DevPanel {
     // bit-sliced barcode scan (lean mode): all barcodes one length bs_m <= 16, k <= 7.
     // bs_re[((p * 16 + row) * 16 + code) * MBW + w] = bitmask over primer p's barcode list: barcode_rc[row] eq code
     int bs_ok, bs_m;
+    int n_bstab;              // distinct per-primer tables in bs_re (primers with the same barcode list share one)
+    const int *bs_tab;        // per primer: its table
     int cap_hits, cap_ents;   // test hook (SMX_TEST_CAPS=h,e): force small barcode rounds; 0 = default sizing
     int no_sp;                // SMX_NO_SPECIALISE (bit 0) / SMX_NO_SPECIALISE_NP (bit 1), read once at smx_panel_create
     const unsigned *bs_re;
@@ -81,7 +83,7 @@ int smx_prescan_set_lds_limit(size_t bytes);
 int smx_prescan_occupancy(int S, int mr, int nx, size_t lds_t, int *blocks_t, int *blocks_d);
 int smx_prescan_transpose_threads(int S);
 size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta, int kidx,
-                           int slots, int bs, int nitems, int ncand, int tails);
+                           int slots, int bs, int nitems, int ncand, int tails, int nbstab);
 int smx_set_demux_lds_limit(int use64, size_t bytes);
 int smx_demux_sp_query(const smx::DevPanel *P, int use64, int use_slots, int cm, int R, int nitems, int have_prescan);
 int smx_query_occupancy(const smx::DevPanel *P, int use64, int use_slots, int cm, int R, int nitems, size_t lds_bytes,

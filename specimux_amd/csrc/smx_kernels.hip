@@ -162,7 +162,7 @@ __host__ __device__ inline bool layout_tie_in_rec(int MBW, int slots, int tails)
 template <typename PW>
 __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, int maxB, int need_starts,
                                                     int npmeta, int kidx, int slots, int bs, int ncand, int cap_hits = 0,
-                                                    int cap_ents = 0, int nitems = 0, int tails = 1) {
+                                                    int cap_ents = 0, int nitems = 0, int tails = 1, int nbstab = -1) {
     // nitems > 0: compact mode.  The tile keeps per-alignment state (hit record, end mask, scan slots) for at most nitems
     // of its R * H alignments -- the ones the prescan's match words flag -- plus one shared "no match" record; hmap maps
     // (read, alignment) to its record.  Panels with many primers spend most of their LDS on alignments that never match.
@@ -185,7 +185,7 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     int fit = slots ? (16 * 1024) / (t.G * 4) : ((nitems > 0 ? 8 : 3) * 1024) / ((kidx + 1) * t.MBW * 4);
     t.CAPH = dense < fit ? dense : (fit < 1 ? 1 : fit);
     t.CAPE = t.CAPH + t.CAPH / 4 < 256 ? 256 : t.CAPH + t.CAPH / 4;   // >= 256 = max locations of one hit (progress)
-    if (nitems > 0) t.CAPE = 2 * t.CAPH < 256 ? 256 : 2 * t.CAPH;     // (noisy reads of a wide window: two optimal ends per hit)
+    if (nitems > 0) t.CAPE = t.CAPH + t.CAPH / 2 < 256 ? 256 : t.CAPH + t.CAPH / 2;   // (noisy reads of a wide window: several optimal ends per hit)
     if (cap_hits > 0 && cap_hits < t.CAPH) t.CAPH = cap_hits;          // test hook: many small rounds
     if (cap_ents >= S && cap_ents < t.CAPE) t.CAPE = cap_ents;         // (a hit has at most S locations)
     // Order: regions whose offsets depend on the tile geometry only (R, S) come first -- compile-time constants in the
@@ -234,7 +234,7 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.prpeq = o; o += (need_starts ? t.NPs * 16 * (int)sizeof(PW) : 0);
     t.bpeq = o;  o += (bs && !slots) ? 0 : t.NBs * 16 * 4;
     t.BSP = 16 * 16 + 4;                        // words per (primer, 32-barcode word) block of the bit-sliced table (+4: bank skew)
-    t.bsre = o;  o += (bs && !slots) ? NP * t.MBW * t.BSP * 4 : 0;
+    t.bsre = o;  o += (bs && !slots) ? (nbstab > 0 ? nbstab : NP) * t.MBW * t.BSP * 4 : 0;   // one table per distinct barcode list
     t.pmeta = o; o += npmeta * 4;
     t.total = (o + 15) & ~15;
     return t;
@@ -523,7 +523,7 @@ __device__ __forceinline__ void bitsliced_shw_pad_tails(const unsigned *re, cons
 // Scorer helpers (phase 4).  Everything is indexed, nothing is string keyed.
 // Small per-panel tables staged in LDS (the scorer and the barcode scan read them constantly).
 struct LPanel {
-    const int *pm, *pk, *pdir, *pfidx, *pbc_off, *pbc, *bm, *pair_f, *pair_r, *pair_pool;
+    const int *pm, *pk, *pdir, *pfidx, *pbc_off, *pbc, *bm, *pair_f, *pair_r, *pair_pool, *bstab;
 };
 
 struct ReadCtx {
@@ -1232,7 +1232,7 @@ struct DemuxTile {
         NP = SP == 2 ? 2 : P->NP; NB = P->NB; S = SP == 3 ? 160 : (sp ? 80 : P->S); H = 2 * NP; MW = (S + 31) / 32; maxB = P->maxB;
         need_starts = sp ? 0 : P->need_starts;
         n_pbc = P->n_pbc; NPAIR = SP == 2 ? 1 : P->NPAIR;
-        npmeta = 5 * NP + 1 + n_pbc + NB + 3 * NPAIR;
+        npmeta = 6 * NP + 1 + n_pbc + NB + 3 * NPAIR;
         // (the default-flags kernels are lean bit-sliced launches by construction: no slots-mode state in them)
         use_slots = SP != 0 ? 0 : use_slots_arg;
         dbg_bdist = SP != 0 ? nullptr : dbg_bdist_arg;
@@ -1240,7 +1240,7 @@ struct DemuxTile {
         ncand = 2 * NPAIR;
         const int tails = sp ? 0 : (P->trim == SMX_TRIM_TAILS ? 1 : 0);
         T = make_layout<PW>(NP, NB, S, R, maxB, need_starts, npmeta, sp ? 3 : P->kidx, use_slots, P->bs_ok, ncand,
-                            sp ? 0 : P->cap_hits, sp ? 0 : P->cap_ents, (sp && CM == 1) ? 256 : aux.nitems, tails);
+                            sp ? 0 : P->cap_hits, sp ? 0 : P->cap_ents, (sp && CM == 1) ? 256 : aux.nitems, tails, P->n_bstab);
         ppeq = (PW *)(lds + T.ppeq);        // [code][primer], stride NPs
         prpeq = (PW *)(lds + T.prpeq);
         bpeq = (unsigned *)(lds + T.bpeq);   // [code][barcode], stride NBs
@@ -1302,7 +1302,7 @@ struct DemuxTile {
         if (!use_bs)
             for (int i = tid; i < NB * 16; i += NT) bpeq[(i & 15) * NBs + (i >> 4)] = P->bpeq[i];
         if (use_bs)
-            for (int i = tid; i < NP * T.MBW * 256; i += NT) {
+            for (int i = tid; i < P->n_bstab * T.MBW * 256; i += NT) {
                 int blk = i >> 8;   // (primer, word) block: [row][code], the row stride is a compile-time 16 words
                 bsre[blk * T.BSP + (i & 255)] = P->bs_re[i];
             }
@@ -1312,7 +1312,9 @@ struct DemuxTile {
             int *q = pmeta;
             LP.pm = q; q += NP; LP.pk = q; q += NP; LP.pdir = q; q += NP; LP.pfidx = q; q += NP;
             LP.pbc_off = q; q += NP + 1; LP.pbc = q; q += n_pbc; LP.bm = q; q += NB;
-            LP.pair_f = q; q += NPAIR; LP.pair_r = q; q += NPAIR; LP.pair_pool = q;
+            LP.pair_f = q; q += NPAIR; LP.pair_r = q; q += NPAIR; LP.pair_pool = q; q += NPAIR;
+            LP.bstab = q;
+            for (int i = tid; i < NP; i += NT) q[i] = P->bs_tab[i];
             for (int i = tid; i < NP; i += NT) {
                 pmeta[i] = P->pm[i]; pmeta[NP + i] = P->pk[i]; pmeta[2 * NP + i] = P->pdir[i]; pmeta[3 * NP + i] = P->pfidx[i];
             }
@@ -1692,7 +1694,7 @@ struct DemuxTile {
                     unsigned seen[4], ML[4];
                     const unsigned want[4] = {~0u, ~0u, ~0u, ~0u};
                     int tc = -1;
-                    const unsigned *reb = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
+                    const unsigned *reb = bsre + __mul24(__mul24(LP.bstab[p], MBW) + w, T.BSP);
                     if (bsm == 13) bitsliced_shw_pad_tails<3, 13>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
                     else if (bsm <= 8 && bsm > 3) bitsliced_shw_pad_tails<3, 8>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
                     else if (bsm <= 12 && bsm > 3) bitsliced_shw_pad_tails<3, 12>(reb, cwt, en.ncol, bsm, kidx, want, seen, ML, tc);
@@ -1706,7 +1708,7 @@ struct DemuxTile {
                 } else if constexpr (BSV == 1) {
                     unsigned seen[4];
                     // padded height: the smallest instantiated M >= barcode length (uniform branch)
-                    const unsigned *reb = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
+                    const unsigned *reb = bsre + __mul24(__mul24(LP.bstab[p], MBW) + w, T.BSP);
                     if (bsm == 13) bitsliced_shw_pad<3, 13>(reb, cwt, en.ncol, bsm, kidx, seen);
                     else if (bsm <= 8 && bsm > 3) bitsliced_shw_pad<3, 8>(reb, cwt, en.ncol, bsm, kidx, seen);
                     else if (bsm <= 12 && bsm > 3) bitsliced_shw_pad<3, 12>(reb, cwt, en.ncol, bsm, kidx, seen);
@@ -1716,7 +1718,7 @@ struct DemuxTile {
                         if (d <= kidx && seen[d]) atomicOr(&dm[d * MBW], seen[d]);
                 } else if constexpr (BSV == 2) {
                     unsigned seen[8];
-                    const unsigned *reb8 = bsre + __mul24(__mul24(p, MBW) + w, T.BSP);
+                    const unsigned *reb8 = bsre + __mul24(__mul24(LP.bstab[p], MBW) + w, T.BSP);
                     if (kidx == 4 && bsm > 4 && bsm <= 16) {   // k = 4: the padded straight-line scan with a 9-row window
                         unsigned s5[5];
                         if (bsm == 13) bitsliced_shw_pad<4, 13>(reb8, cwt, en.ncol, bsm, kidx, s5);
@@ -1798,7 +1800,7 @@ struct DemuxTile {
                             const int dn = cmode ? (int)clist[item] : item;
                             const int r = divH(dn), h = dn - __mul24(r, H), p = h >> 1, X = h & 1;
                             const int base = end_geom(lensC[r], S).base, bsm = P->bs_m;
-                            const unsigned *reb = bsre + __mul24(p, T.BSP);   // MBW == 1 on this path
+                            const unsigned *reb = bsre + __mul24(LP.bstab[p], T.BSP);   // MBW == 1 on this path
                             unsigned GM[4], prev[4] = {0u, 0u, 0u, 0u}, lower = 0;
 #pragma unroll
                             for (int d = 0; d < 4; d++) { GM[d] = d <= kidx ? (dm[d] & ~lower) : 0u; lower |= d <= kidx ? dm[d] : 0u; }
@@ -2416,9 +2418,9 @@ extern "C" int smx_launch_demux(const smx::DevPanel *P, int use64, int R, int gr
 }
 
 extern "C" size_t smx_demux_lds_bytes(int use64, int NP, int NB, int S, int R, int maxB, int need_starts, int npmeta,
-                                      int kidx, int slots, int bs, int nitems, int ncand, int tails) {
-    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, ncand, 0, 0, nitems, tails).total
-                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, ncand, 0, 0, nitems, tails).total;
+                                      int kidx, int slots, int bs, int nitems, int ncand, int tails, int nbstab) {
+    return use64 ? (size_t)smx::make_layout<unsigned long long>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, ncand, 0, 0, nitems, tails, nbstab).total
+                 : (size_t)smx::make_layout<unsigned>(NP, NB, S, R, maxB, need_starts, npmeta, kidx, slots, bs, ncand, 0, 0, nitems, tails, nbstab).total;
 }
 
 extern "C" int smx_set_demux_lds_limit(int use64, size_t bytes) {

@@ -155,7 +155,6 @@ struct smx_panel {
     // for the nitems alignments the match words flag; a tile that needs more goes on the overflow list and is redone by a
     // dense launch (R, lds) right behind the compact one.  nitems == 0: off.
     int Rc = 0, nitems = 0, blocks_per_cu_c = 1;
-    int env_stream_slots = 0;
     int share = 1;      // smx_panel_set_streams: batches the caller keeps in flight on as many streams
     size_t lds_c = 0;
     DevBuf ovf[SMX_MAX_STREAMS];             // per stream slot: overflow list, one entry per compact tile
@@ -319,7 +318,6 @@ int smx_panel_create(const smx_panel_desc *d, smx_panel **out) {
     P->env_force_slots = getenv("SMX_FORCE_SLOTS") != nullptr;
     P->env_debug_overflow = getenv("SMX_DEBUG_OVERFLOW") != nullptr;
     P->env_debug = getenv("SMX_DEBUG") != nullptr;
-    if (const char *e = getenv("SMX_STREAM_SLOTS")) P->env_stream_slots = atoi(e);
     h.bs_m = bm[0];
     if (h.pfmin != 0 && h.pfmin < 2) { delete P; return fail(SMX_ERR_UNSUPPORTED, "prefilter min length %d < 2: disable the prefilter", h.pfmin); }
     if (h.bmax + h.kidx > 200) { delete P; return fail(SMX_ERR_UNSUPPORTED, "barcode length + k too large"); }
@@ -707,7 +705,6 @@ int smx_batch_run_device(const smx_panel *Pc, void *stream, const uint8_t *d_win
         // two launches side by side must not claim more slots than the CU has: nothing of the next batch's prescan kernels
         // would fit beside them (five slots, two streams: 3 + 3 measured 0.335 ms per step, 2 + 2 0.306-0.319)
         if (P->share == 2 && per * 2 > blocks) per = std::max(1, blocks / 2);
-        if (P->env_stream_slots > 0 && P->share > 1) per = std::min(blocks, P->env_stream_slots);   // tuning hook (SMX_STREAM_SLOTS)
         return (uint32_t)(P->n_cu * per);
     };
     int grid = (int)std::min<uint32_t>(tiles, slots_of(use_slots ? P->blocks_per_cu_slots : P->blocks_per_cu));

@@ -222,7 +222,7 @@ __host__ __device__ inline TileLayout make_layout(int NP, int NB, int S, int R, 
     t.masks = t.emit = o; o += t.NI * MW * 4;
     o = (o + 3) & ~3;
     t.offsA = o; o += ((t.NI + 2) & ~1) * 2;   // 16-bit scans: a tile has at most NI * S < 65536 locations
-    t.offsB = o; o += ((t.NI + 2) & ~1) * 2;   // (>= 16 bytes: the one-round path parks four wave sums here)
+    t.offsB = o; o += ((t.NI + 2) & ~1) * 2 < 16 ? 16 : ((t.NI + 2) & ~1) * 2;   // (>= 16 bytes: the one-round path parks four wave sums here)
     t.queue = o; o += ((t.NI + 1) & ~1) * 2;
     if (o < t.emit + R * ncand * 4) o = t.emit + R * ncand * 4;
     o = (o + 7) & ~7;

@@ -68,6 +68,23 @@ def test_edit_distance_equals_oracle_nw():
         assert edit_distance(a, b) == E.align(a, b, E.NW, -1, iupac=False)["editDistance"], (a, b)
 
 
+def test_native_min_pairwise_distance_equals_python_loop():
+    """setup_match_parameters takes its barcode distances from libsmx (smx_min_pairwise_distance); the Python bit-parallel
+    edit_distance stays as the checker: random sets of equal and ragged lengths, duplicates (distance 0), the empty
+    string, a set large enough for the threaded path, and non-ASCII text (falls back to the Python loop)."""
+    import itertools
+    from specimux_amd.orchestration import _native_min_pairwise, edit_distance
+    rng = np.random.default_rng(11)
+
+    def rand_seq(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    cases = [[rand_seq(13) for _ in range(40)], [rand_seq(int(rng.integers(5, 20))) for _ in range(30)],
+             ["ACGT", "ACGT", "TTTT"], ["", "ACG"], [rand_seq(12) for _ in range(100)], ["AÇGT", "ACGT", "AGGT"]]
+    for seqs in cases:
+        exp = min(edit_distance(x, y) for x, y in itertools.combinations(seqs, 2))
+        assert _native_min_pairwise(seqs) == exp, seqs[:3]
+
+
 def test_panel_compiler_flattening():
     from specimux_amd.demultiplex import compiled_panel
     both = Both(P, S)

@@ -847,8 +847,10 @@ int write_one(smx_writer *w, smx_writer::Shard &sh, uint32_t me, uint32_t T, con
             }
         }
     }
-    if (mine1 && sh.files[f1].bytes > w->flush_bytes) smx_writer::flush(sh, sh.files[f1]);
-    if (mine2 && sh.files[f2].bytes > w->flush_bytes) smx_writer::flush(sh, sh.files[f2]);
+    // (at most ~1000 pieces pending: a flush is then ONE writev, i.e. one append that no other process's append can land
+    // inside -- ranks of a multi-GPU run append to the same files, specimux_amd/distributed.py)
+    if (mine1 && (sh.files[f1].bytes > w->flush_bytes || sh.files[f1].pieces.size() > 960)) smx_writer::flush(sh, sh.files[f1]);
+    if (mine2 && (sh.files[f2].bytes > w->flush_bytes || sh.files[f2].pieces.size() > 960)) smx_writer::flush(sh, sh.files[f2]);
     return SMX_OK;
 }
 

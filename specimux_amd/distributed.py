@@ -112,6 +112,27 @@ def rank_dir(output_dir, rank):
 ST_OK, ST_CANNOT_CUT, ST_ERROR = 0, 1, 2
 
 
+def _validate_shard(sequence_file, byte_range):
+    """Parse the records of a byte range without keeping them: ST_OK, ST_CANNOT_CUT (compressed input, FASTA, wrapped FASTQ:
+    only a reader of the whole file can deliver the records) or ST_ERROR."""
+    from . import _lib
+    from .native_io import Reader
+    try:
+        reader = Reader(sequence_file, byte_range=byte_range)
+        try:
+            while True:
+                b = reader.next_batch(262144, 256 << 20)
+                if b is None:
+                    return ST_OK
+                b.close()
+        finally:
+            reader.close()
+    except _lib.SmxError as e:
+        return ST_CANNOT_CUT if e.code == _lib.ERR_UNSUPPORTED else ST_ERROR
+    except Exception:   # noqa: BLE001 -- agreed on by all ranks, raised by the caller
+        return ST_ERROR
+
+
 def run_sharded(sequence_file, output_dir, prefix, counts_len, shard_runner, backend=None, window=None):
     """One input file over WORLD_SIZE processes (one per GPU, launched by torch.distributed.run before anything touches
     a GPU).  Rank k demultiplexes the records that start inside its byte range into its own tree
@@ -119,7 +140,19 @@ def run_sharded(sequence_file, output_dir, prefix, counts_len, shard_runner, bac
     `stride` = (rank, world) instead of a byte range when the file cannot be cut -- gzip, FASTA, wrapped FASTQ -- or when
     the run is restricted to a record window, `window` = True: -n start,num counts records from the start of the file,
     which only a reader of the whole file can do), the counts vectors are summed over the ranks with one all-reduce
-    (RCCL through the C ABI on GPUs), and all ranks merge the trees in parallel (merge_rank_trees).
+    (RCCL through the C ABI on GPUs).
+
+    Where the records go.  Default: every rank APPENDS to the files of the one output tree, as the reference's worker
+    processes do under their per-file lock (io_utils.py:108-121): the native writer hands a file's pending records to the
+    kernel as one O_APPEND writev per flush, which a local file system (tmpfs, ext4, xfs) serialises per inode, so records
+    of different ranks interleave in whole flushes and never inside a record.  Like the reference's, the order of records
+    inside a file is then not the input order.  Because nothing written can be taken back, a byte-range shard is parsed
+    once WITHOUT writing first (a few per cent of the run) so that the ranks agree on byte ranges or batch striding before
+    the first record is out.  SMX_RANK_MERGE=1: every rank writes its own tree <out>/.smx_rank_k and all ranks merge the
+    trees in parallel (merge_rank_trees): every file then holds its records in input order, exactly like a single-process
+    run, at the price of copying (world - 1) / world of the output once more (two ranks sharing one GPU and its 16 host
+    cores, 765 000 reads: 0.73-0.76 s against 0.52-0.55 s; `tools/two_rank_e2e.py`).
+
     A failure on one rank is agreed on by all ranks (one MAX all-reduce of a status word) before anybody raises, so no
     rank is left waiting in a collective.  Returns (global total, global matched, global counts, world) on every rank."""
     import glob
@@ -164,18 +197,32 @@ def run_sharded(sequence_file, output_dir, prefix, counts_len, shard_runner, bac
             for stale in glob.glob(os.path.join(output_dir, ".smx_rank_*")):
                 shutil.rmtree(stale, ignore_errors=True)
         dist.barrier()
-        out = rank_dir(output_dir, rank)
-        os.makedirs(out, exist_ok=True)
+        merge_mode = bool(os.environ.get("SMX_RANK_MERGE"))
         size = os.path.getsize(sequence_file)
-        status, res = (ST_CANNOT_CUT, None) if window else attempt(shard_range(size, rank, world), None)
-        worst = agree(status)
-        if worst == ST_CANNOT_CUT:   # every rank switches to batch striding, or none
-            shutil.rmtree(out, ignore_errors=True)
+        if merge_mode:
+            out = rank_dir(output_dir, rank)
             os.makedirs(out, exist_ok=True)
-            status, res = attempt(None, (rank, world))
+            status, res = (ST_CANNOT_CUT, None) if window else attempt(shard_range(size, rank, world), None)
+            worst = agree(status)
+            if worst == ST_CANNOT_CUT:   # every rank switches to batch striding, or none
+                shutil.rmtree(out, ignore_errors=True)
+                os.makedirs(out, exist_ok=True)
+                status, res = attempt(None, (rank, world))
+                worst = agree(status)
+        else:
+            out = output_dir
+            os.makedirs(out, exist_ok=True)
+            cut = ST_CANNOT_CUT if window else _validate_shard(sequence_file, shard_range(size, rank, world))
+            cut = agree(cut)
+            if cut == ST_ERROR:
+                raise RuntimeError(f"{sequence_file}: the input could not be parsed (this rank or another; see the messages)")
+            status, res = attempt(None, (rank, world)) if cut == ST_CANNOT_CUT else attempt(shard_range(size, rank, world), None)
+            if status == ST_CANNOT_CUT:   # cannot happen after the validation pass; never silently
+                status = ST_ERROR
             worst = agree(status)
         if worst != ST_OK:
-            shutil.rmtree(out, ignore_errors=True)
+            if merge_mode:
+                shutil.rmtree(out, ignore_errors=True)
             if status != ST_OK:
                 raise res
             raise RuntimeError("another rank failed while demultiplexing its shard (see its message)")
@@ -188,11 +235,12 @@ def run_sharded(sequence_file, output_dir, prefix, counts_len, shard_runner, bac
             torch.cuda.synchronize()
         reducer.close()
         gcounts = t.cpu().numpy().astype(np.uint64)
-        dist.barrier()          # every rank's tree is complete and closed
-        merge_rank_trees(output_dir, world, rank, world)
-        dist.barrier()          # every output file is complete
-        remove_rank_tree(output_dir, rank)
-        dist.barrier()
+        dist.barrier()          # every rank's records are written and its files closed
+        if merge_mode:
+            merge_rank_trees(output_dir, world, rank, world)
+            dist.barrier()          # every output file is complete
+            remove_rank_tree(output_dir, rank)
+            dist.barrier()
         return int(gcounts[0]), int(gcounts[1]), gcounts, world
     finally:
         if own_group:

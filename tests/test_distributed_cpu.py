@@ -111,9 +111,12 @@ def _file_worker(rank, world, port, tmp, seqfile, pf, sf):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("kind,world", [("fastq", 2), ("gz", 2), ("fastq", 8)])
-def test_two_rank_file_path_equals_single_process(tmp_path, kind, world):
-    """`specimux -F` under a 2-process launch (and an 8-process one: north_star's node size, rehearsed on gloo): byte-range shards (stride fallback for gzip), per-rank trees, one
+@pytest.mark.parametrize("kind,world,mode", [("fastq", 2, "append"), ("fastq", 2, "merge"), ("gz", 2, "append"), ("gz", 2, "merge"),
+                                             ("fastq", 8, "append"), ("fastq", 8, "merge")])
+def test_two_rank_file_path_equals_single_process(tmp_path, kind, world, mode, monkeypatch):
+    """`specimux -F` under a 2-process launch (and an 8-process one: north_star's node size, rehearsed on gloo), in both
+    output modes of run_sharded: ranks appending to the one tree (default; same records per file, any order, no record
+    torn), and per-rank trees merged (SMX_RANK_MERGE=1; every file in input order). byte-range shards (stride fallback for gzip), per-rank trees, one
     all-reduce of the counts, merge by rank 0.  The merged tree equals the single-process tree FILE BY FILE (records in
     input order), and each specimen's counter equals the records in full/<pool>/<specimen>.fastq."""
     import gzip
@@ -131,6 +134,10 @@ def test_two_rank_file_path_equals_single_process(tmp_path, kind, world):
             shutil.copyfileobj(a, b)
         seqfile += ".gz"
     port = 29500 + ((os.getpid() + 7) % 2000)
+    if mode == "merge":
+        monkeypatch.setenv("SMX_RANK_MERGE", "1")
+    else:
+        monkeypatch.delenv("SMX_RANK_MERGE", raising=False)
     mp.spawn(_file_worker, args=(world, port, os.fspath(tmp_path), seqfile, pf, sf), nprocs=world, join=True)
     exp_tree, total, matched = O.run_files(pf, sf, seqfile)
     got = {}
@@ -140,9 +147,9 @@ def test_two_rank_file_path_equals_single_process(tmp_path, kind, world):
         for fn in files:
             full = os.path.join(dirpath, fn)
             got[os.path.relpath(full, out)] = open(full).read()
-    if kind == "fastq":   # byte ranges keep the input order inside every file
+    if kind == "fastq" and mode == "merge":   # byte ranges + merge keep the input order inside every file
         assert got == {k: "".join(v) for k, v in exp_tree.items()}
-    else:                 # stride sharding interleaves batches: same records, file by file
+    else:                 # appending ranks / stride sharding interleave batches: same records, file by file, none torn
         assert {k: sorted(v.split("@read")) for k, v in got.items()} == {k: sorted("".join(v).split("@read")) for k, v in exp_tree.items()}
     g0 = np.load(tmp_path / "gcounts_0.npy")
     for r in range(1, world):
@@ -216,10 +223,16 @@ def _failing_worker(rank, world, port, tmp, seqfile):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_failure_is_raised_on_every_rank(tmp_path):
+@pytest.mark.parametrize("mode", ["append", "merge"])
+def test_two_rank_failure_is_raised_on_every_rank(tmp_path, mode, monkeypatch):
     """An exception in one rank's shard must not leave the other rank waiting in the counts all-reduce: the ranks agree on a
-    status word first, the failing rank re-raises its exception, the other raises too, no tree is merged, and a stale rank
-    tree left by an earlier (killed) run is gone."""
+    status word first, the failing rank re-raises its exception, the other raises too, and a stale rank tree left by an
+    earlier (killed) run is gone.  With per-rank trees (SMX_RANK_MERGE=1) no tree is merged; ranks that append to the one
+    tree leave what they wrote before the failure, as a failing single-process run does."""
+    if mode == "merge":
+        monkeypatch.setenv("SMX_RANK_MERGE", "1")
+    else:
+        monkeypatch.delenv("SMX_RANK_MERGE", raising=False)
     from specimux_amd.distributed import rank_dir
     seqfile = tmp_path / "reads.fastq"
     seqfile.write_text("@a\nACGT\n+\nIIII\n" * 50)
@@ -232,4 +245,5 @@ def test_two_rank_failure_is_raised_on_every_rank(tmp_path):
     assert o1 == "ValueError: rank 1 cannot read its shard"
     assert o0.startswith("RuntimeError: another rank failed")
     assert not os.path.exists(stale)
-    assert not (tmp_path / "out" / "x.fastq").exists()
+    if mode == "merge":
+        assert not (tmp_path / "out" / "x.fastq").exists()

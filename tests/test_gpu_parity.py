@@ -563,10 +563,13 @@ def test_cli_end_to_end_synthetic(lib, c2, tmp_path, variant):
     assert f"Processed {total:,} sequences, match rate: {matched / total:.1%}" in log
 
 
-def test_cli_two_rank_launch_equals_single_process(lib, c2, tmp_path):
+@pytest.mark.parametrize("mode", ["append", "merge"])
+def test_cli_two_rank_launch_equals_single_process(lib, c2, tmp_path, mode):
     """The product multi-GPU path for files, rehearsed with two ranks on this one GPU (gloo for the counts, since RCCL
     refuses two ranks per device): `python -m torch.distributed.run --nproc-per-node 2 -m specimux_amd.cli ... -F`.
-    Byte-range shards, per-rank trees, merge: the tree is identical, file by file, to the single-process run."""
+    Byte-range shards; default: both ranks append to the one tree (same records in every file as the single-process run,
+    none torn, order free as in the reference's worker pool); SMX_RANK_MERGE=1: per-rank trees, merged -- the tree is
+    identical, byte for byte, to the single-process run."""
     import os
     import subprocess
     import sys
@@ -580,6 +583,9 @@ def test_cli_two_rank_launch_equals_single_process(lib, c2, tmp_path):
     cli.main(["specimux", pf, sf, str(fq), "-F", "-O", str(one)])
     two = tmp_path / "two"
     env = dict(os.environ, SMX_DIST_BACKEND="gloo", PYTHONPATH=REPO)
+    env.pop("SMX_RANK_MERGE", None)
+    if mode == "merge":
+        env["SMX_RANK_MERGE"] = "1"
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                     "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), "-m", "specimux_amd.cli", pf, sf, str(fq),
                     "-F", "-O", str(two)], check=True, env=env, timeout=600, cwd=REPO)
@@ -589,10 +595,12 @@ def test_cli_two_rank_launch_equals_single_process(lib, c2, tmp_path):
         for dirpath, _d, files in os.walk(root):
             for fn in files:
                 if fn != "log.txt":
-                    out[os.path.relpath(os.path.join(dirpath, fn), root)] = open(os.path.join(dirpath, fn)).read()
+                    text = open(os.path.join(dirpath, fn)).read()
+                    out[os.path.relpath(os.path.join(dirpath, fn), root)] = text if mode == "merge" else sorted(text.split("@read"))
         return out
     a, b = tree(one), tree(two)
     assert a == b and sum(1 for k in a if k.startswith("full/")) > 100
+    assert not any(n.startswith(".smx_rank_") for n in os.listdir(two))
     log = (two / "log.txt").read_text()
     assert "Demultiplexed on 2 GPUs" in log and "Processed 3,000 sequences" in log
 

@@ -248,8 +248,9 @@ def _run_native(args):
     panel = compiled_panel(specimens, parameters, args, prefilter)
     if world > 1:
         # one process per GPU (python -m torch.distributed.run ... -m specimux_amd.cli ...): the input file is cut
-        # into byte ranges at record boundaries, every rank writes its own tree, one RCCL all-reduce sums the counts,
-        # all ranks merge (specimux_amd/distributed.py; reference: the worker pool of orchestration.py:181-207).
+        # into byte ranges at record boundaries, every rank appends its records to the one output tree (or writes its own
+        # tree, merged afterwards: SMX_RANK_MERGE=1), one RCCL all-reduce sums the counts
+        # (specimux_amd/distributed.py; reference: the worker pool of orchestration.py:181-207).
         # -n start,num (cli.py:54-68, orchestration.py:170-172) counts records from the start of the file: every rank then
         # reads the whole file, applies the window, and keeps batch i iff i mod world == rank (batch striding).
         from .distributed import run_sharded

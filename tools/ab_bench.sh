@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: kernel-resident bench (no CPU baseline, no extras) for c2 / c3 / c5 under a list of environments.
-#   tools/ab_bench.sh "SMX_DP_RS=0" "SMX_DP_RS=1" ...   -> one line per (env, config): reads/s, step ms, kernel ms
+#   tools/ab_bench.sh "SMX_COMPACT=0" "SMX_NO_SPECIALISE=1" ...   -> one line per (env, config): reads/s, step ms, kernel ms
 for envs in "$@"; do
   for cfg in c2 c3 c5; do
     reads=765000; [ $cfg != c2 ] && reads=1000000

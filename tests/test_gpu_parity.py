@@ -697,11 +697,13 @@ def test_forced_small_barcode_rounds(c2, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [dict(), dict(SMX_COMPACT_ITEMS="40"), dict(SMX_COMPACT_ITEMS="16", SMX_COMPACT_R="24"),
-                                 dict(SMX_COMPACT="0")], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
+                                 dict(SMX_COMPACT="0"), dict(SMX_NO_TABLE_SHARING="1")],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
 def test_compact_tiles_many_primer_panel(lib, c3, monkeypatch, env):
     """The lean kernel's compact mode (panels with many primers: per-alignment records only for the alignments the
     prescan's match words flag) and the dense redo launch behind it.  Default sizing, a record capacity small enough
-    that most tiles overflow into the redo launch, a tile size that is not a power of two, and compact mode off: the
+    that most tiles overflow into the redo launch, a tile size that is not a power of two, compact mode off, and one
+    barcode table per primer instead of one per distinct barcode list (this panel's eight primers share two): the
     same records and hit tables as the oracle every time -- including reads with N (not covered by the prescan: every
     alignment of such a read takes a record) and short reads."""
     from specimux_amd import synth

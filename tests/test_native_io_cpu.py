@@ -404,3 +404,31 @@ def test_white_space_inside_a_sequence_line_leaves_the_fast_engine(tmp_path, pos
     exp, _ = O.read_sequences(os.fspath(fq))     # the oracle's line-based parser (Bio.SeqIO semantics)
     assert got == [tuple(r) for r in exp]
     assert [g[0] for g in got] == ["a", "b", "c"] and got[0] == recs[0] and got[2] == recs[2]
+
+
+def test_writer_many_tiny_records_flush_by_piece_count(tmp_path, monkeypatch):
+    """A flush is ONE writev (ranks of a multi-GPU run append to the same files: specimux_amd/distributed.py), so a file's
+    pending pieces are capped near 1000 whatever their bytes: 6000 trimmed 12-base records for one file are some 24 000
+    pieces, far below the 64 KB byte threshold per flush at a time -- every record must arrive, in order, untorn."""
+    from specimux_amd import _lib
+    from specimux_amd.native_io import Reader, Writer
+
+    class FakePanel:
+        specimen_ids, pools, primer_names, barcodes = ["s"], ["P"], ["F", "R"], ["ACGT"]
+    monkeypatch.setenv("SMX_IO_THREADS", "4")
+    n = 6000
+    rng = np.random.default_rng(9)
+    seqs = ["".join("ACGT"[i] for i in rng.integers(0, 4, 12)) for _ in range(n)]
+    fq = tmp_path / "tiny.fastq"
+    fq.write_text("".join(f"@t{i}\n{s}\n+\n{'I' * 12}\n" for i, s in enumerate(seqs)))
+    batch = Reader(os.fspath(fq)).next_batch(n + 1)
+    assert len(batch) == n
+    ops = np.zeros(n, dtype=_lib.OP_DTYPE)
+    for i in range(n):
+        ops[i] = (0, 2, 10, 0, 0, 1, -1, [0, 0, 0, 0], _lib.R_DEREP_FULL, 0, 1, i)
+    w = Writer(os.fspath(tmp_path / "o"), "", True, FakePanel)
+    w.write(batch, ops, np.zeros(0, dtype=_lib.OP_DTYPE))
+    w.close()
+    exp = "".join(f"@t{i} 0,0,0,0 pool=P primers=F+R s\n{s[2:10]}\n+\nIIIIIIII\n" for i, s in enumerate(seqs))
+    assert (tmp_path / "o/full/P/F-R/s.fastq").read_text() == exp
+    assert (tmp_path / "o/full/P/s.fastq").read_text() == exp
